@@ -1,0 +1,301 @@
+"""ctypes binding of the C ABI in include/hgibbs.h (libhgibbs.so, HIP/gfx950).
+
+This is plumbing only: every compute entry point lives in the shared library.
+There is no CPU fallback -- if the library is missing or no gfx950 device is
+visible the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhgibbs.so")
+
+# every symbol include/hgibbs.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "hgibbs_last_error", "hgibbs_version", "hgibbs_create", "hgibbs_destroy", "hgibbs_comm_unique_id",
+    "hgibbs_comm_init", "hgibbs_load_bed", "hgibbs_synth_bed", "hgibbs_dims", "hgibbs_get_bed",
+    "hgibbs_marker_stats", "hgibbs_set_residual", "hgibbs_get_residual", "hgibbs_reduce_eps", "hgibbs_add_scalar",
+    "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
+    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
+    "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
+    "hydra_chain_last_nnz",
+]
+
+
+class RngState(C.Structure):
+    _fields_ = [("x", C.c_uint32 * 624), ("idx", C.c_uint32)]
+
+
+class SweepStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("device_ms", C.c_double),
+                ("kernel_ms_avg", C.c_double)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("shuffle", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
+                ("groups", C.POINTER(C.c_int32)), ("mS", C.POINTER(C.c_double))]
+
+
+class HgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HgError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    u8p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.hgibbs_last_error.restype = C.c_char_p
+    L.hgibbs_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.hgibbs_destroy.argtypes = [vp]
+    L.hgibbs_comm_unique_id.argtypes = [C.c_void_p]
+    L.hgibbs_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.hgibbs_load_bed.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.hgibbs_synth_bed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double]
+    L.hgibbs_dims.argtypes = [vp, u32p, u32p, u32p, u32p]
+    L.hgibbs_get_bed.argtypes = [vp, C.c_uint32, C.c_uint32, u8p, C.c_uint64]
+    L.hgibbs_marker_stats.argtypes = [vp, dp, dp, u64p, u64p, u64p]
+    L.hgibbs_set_residual.argtypes = [vp, dp]
+    L.hgibbs_get_residual.argtypes = [vp, dp]
+    L.hgibbs_reduce_eps.argtypes = [vp, dp, dp]
+    L.hgibbs_add_scalar.argtypes = [vp, C.c_double]
+    L.hgibbs_update_marker.argtypes = [vp, C.c_uint32, C.c_double]
+    L.hgibbs_dot_marker.argtypes = [vp, C.c_uint32, dp]
+    L.hgibbs_set_model.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
+    L.hgibbs_set_beta.argtypes = [vp, dp]
+    L.hgibbs_get_beta.argtypes = [vp, dp, ip, dp]
+    L.hgibbs_beta_sqnorm.argtypes = [vp, dp]
+    L.hgibbs_sweep.argtypes = [vp, ip, C.c_double, dp, dp, u8p, C.POINTER(RngState), ip, u64p]
+    L.hgibbs_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.hgibbs_last_sweep_stats.argtypes = [vp, C.POINTER(SweepStats)]
+    L.hydra_chain_create.argtypes = [vp, C.POINTER(ModelDesc), dp, C.POINTER(vp)]
+    L.hydra_chain_destroy.argtypes = [vp]
+    L.hydra_chain_iterate.argtypes = [vp]
+    L.hydra_chain_state.argtypes = [vp, dp, dp, dp, dp, ip, ip, C.POINTER(RngState)]
+    L.hydra_chain_csv_line.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.hydra_chain_order.argtypes = [vp]
+    L.hydra_chain_order.restype = ip
+    L.hydra_chain_last_nnz.argtypes = [vp]
+    L.hydra_chain_last_nnz.restype = C.c_uint64
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise HgError(lib().hgibbs_last_error().decode(errors="replace"))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _u64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class Device:
+    """One GPU's share of the problem (hgibbs_t)."""
+
+    def __init__(self, device_id=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        check(self.L.hgibbs_create(device_id, C.byref(self.h)))
+        self.M = self.n_local = self.n_global = self.row_begin = 0
+        self.G = self.K = 0
+
+    def close(self):
+        if self.h:
+            self.L.hgibbs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- distributed --
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().hgibbs_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid) if uid else None
+        check(self.L.hgibbs_comm_init(self.h, nranks, rank, buf))
+
+    # -- data --
+    def _dims(self):
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self.L.hgibbs_dims(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self.n_global, self.n_local, self.M, self.row_begin = a.value, b.value, c.value, d.value
+
+    def load_bed(self, bed, n_total, keep=None, row_begin=0, row_end=None, n_global=None):
+        bed = np.ascontiguousarray(bed, dtype=np.uint8)
+        M, stride = bed.shape
+        kept = int(np.count_nonzero(keep)) if keep is not None else n_total
+        if row_end is None:
+            row_end = kept
+        if n_global is None:
+            n_global = kept
+        kp = _u8(np.ascontiguousarray(keep, dtype=np.uint8)) if keep is not None else None
+        check(self.L.hgibbs_load_bed(self.h, _u8(bed), stride, n_total, M, kp, row_begin, row_end, n_global))
+        self._dims()
+
+    def synth_bed(self, n_global, M, seed=42, missing_rate=0.0, row_begin=0, row_end=None):
+        if row_end is None:
+            row_end = n_global
+        check(self.L.hgibbs_synth_bed(self.h, n_global, M, row_begin, row_end, seed, missing_rate))
+        self._dims()
+
+    def get_bed(self, m0=0, mcount=None):
+        if mcount is None:
+            mcount = self.M - m0
+        out = np.zeros((mcount, (self.n_local + 3) // 4), dtype=np.uint8)
+        check(self.L.hgibbs_get_bed(self.h, m0, mcount, _u8(out), out.shape[1]))
+        return out
+
+    def marker_stats(self):
+        M = self.M
+        mave, mstd = np.zeros(M), np.zeros(M)
+        n1, n2, nm = (np.zeros(M, dtype=np.uint64) for _ in range(3))
+        check(self.L.hgibbs_marker_stats(self.h, _dp(mave), _dp(mstd), _u64(n1), _u64(n2), _u64(nm)))
+        return mave, mstd, n1, n2, nm
+
+    def set_residual(self, eps):
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
+        assert eps.shape[0] == self.n_local
+        check(self.L.hgibbs_set_residual(self.h, _dp(eps)))
+
+    def get_residual(self):
+        out = np.zeros(self.n_local)
+        check(self.L.hgibbs_get_residual(self.h, _dp(out)))
+        return out
+
+    def reduce_eps(self):
+        s, q = C.c_double(), C.c_double()
+        check(self.L.hgibbs_reduce_eps(self.h, C.byref(s), C.byref(q)))
+        return s.value, q.value
+
+    def add_scalar(self, c):
+        check(self.L.hgibbs_add_scalar(self.h, c))
+
+    def update_marker(self, marker, dbeta):
+        check(self.L.hgibbs_update_marker(self.h, marker, dbeta))
+
+    def dot_marker(self, marker):
+        v = C.c_double()
+        check(self.L.hgibbs_dot_marker(self.h, marker, C.byref(v)))
+        return v.value
+
+    def set_model(self, groups, cVa, cVaI):
+        cVa = np.ascontiguousarray(cVa, dtype=np.float64)
+        cVaI = np.ascontiguousarray(cVaI, dtype=np.float64)
+        G, K = cVa.shape
+        g = _ip(np.ascontiguousarray(groups, dtype=np.int32)) if groups is not None else None
+        check(self.L.hgibbs_set_model(self.h, G, K, g, _dp(cVa), _dp(cVaI)))
+        self.G, self.K = G, K
+
+    def set_beta(self, beta):
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        check(self.L.hgibbs_set_beta(self.h, _dp(beta)))
+
+    def get_beta(self):
+        beta, comp, acum = np.zeros(self.M), np.zeros(self.M, dtype=np.int32), np.zeros(self.M)
+        check(self.L.hgibbs_get_beta(self.h, _dp(beta), _ip(comp), _dp(acum)))
+        return beta, comp, acum
+
+    def beta_sqnorm(self):
+        out = np.zeros(self.G)
+        check(self.L.hgibbs_beta_sqnorm(self.h, _dp(out)))
+        return out
+
+    def set_option(self, name, value):
+        check(self.L.hgibbs_set_option(self.h, name.encode(), int(value)))
+
+    def sweep(self, order, sigmaE, sigmaG, estPi, adaV, rng):
+        """rng: RngState, updated in place.  Returns (cass[G,K], nnz_updates)."""
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        sigmaG = np.ascontiguousarray(sigmaG, dtype=np.float64)
+        estPi = np.ascontiguousarray(estPi, dtype=np.float64)
+        adaV = np.ascontiguousarray(adaV, dtype=np.uint8)
+        cass = np.zeros((self.G, self.K), dtype=np.int32)
+        nnz = C.c_uint64()
+        check(self.L.hgibbs_sweep(self.h, _ip(order), float(sigmaE), _dp(sigmaG), _dp(estPi), _u8(adaV), C.byref(rng),
+                                  _ip(cass), C.byref(nnz)))
+        return cass, nnz.value
+
+    def sweep_stats(self):
+        s = SweepStats()
+        check(self.L.hgibbs_last_sweep_stats(self.h, C.byref(s)))
+        return {"launches": s.launches, "nnz_updates": s.nnz_updates, "device_ms": s.device_ms,
+                "kernel_ms_avg": s.kernel_ms_avg}
+
+
+class Chain:
+    """hydra_chain_t: the runMpiGibbs body on top of a loaded Device."""
+
+    def __init__(self, dev, y, mS=None, groups=None, seed=1222, shuffle=1):
+        self.dev = dev
+        self.L = dev.L
+        if mS is None:
+            mS = np.array([[0.0, 0.0001, 0.001, 0.01]])
+        self.mS = np.ascontiguousarray(mS, dtype=np.float64)
+        self.G, self.K = self.mS.shape
+        self.groups = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.shape[0] == dev.n_global
+        d = ModelDesc(seed, shuffle, self.G, self.K, _ip(self.groups) if self.groups is not None else None, _dp(self.mS))
+        self.h = C.c_void_p()
+        check(self.L.hydra_chain_create(dev.h, C.byref(d), _dp(y), C.byref(self.h)))
+        dev.G, dev.K = self.G, self.K
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.hydra_chain_destroy(self.h)
+        except Exception:
+            pass
+
+    def iterate(self):
+        check(self.L.hydra_chain_iterate(self.h))
+
+    def state(self):
+        G, K = self.G, self.K
+        sE, mu = C.c_double(), C.c_double()
+        sG, pi = np.zeros(G), np.zeros((G, K))
+        m0, cass = np.zeros(G, dtype=np.int32), np.zeros((G, K), dtype=np.int32)
+        rng = RngState()
+        check(self.L.hydra_chain_state(self.h, C.byref(sE), C.byref(mu), _dp(sG), _dp(pi), _ip(m0), _ip(cass), C.byref(rng)))
+        return {"sigmaE": sE.value, "mu": mu.value, "sigmaG": sG, "estPi": pi, "m0": m0, "cass": cass,
+                "rng_x": np.array(rng.x, dtype=np.uint32), "rng_idx": int(rng.idx)}
+
+    def order(self):
+        return np.ctypeslib.as_array(self.L.hydra_chain_order(self.h), shape=(self.dev.M,)).copy()
+
+    def last_nnz(self):
+        return int(self.L.hydra_chain_last_nnz(self.h))
+
+    def csv_line(self, it):
+        buf = C.create_string_buffer(50000)
+        n = self.L.hydra_chain_csv_line(self.h, it, buf, 50000)
+        return buf.raw[:n].decode()

@@ -1,0 +1,170 @@
+// hg_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// BayesRR per-marker hot path.  No MFMA: the path is a byte-decode + masked
+// fp64 reduction, bound by HBM/L2 traffic and launch/hand-off latency.
+//
+// Data layout in HBM (per GPU, individuals shard [row_begin,row_end)):
+//   bed    M columns x stride bytes, stride = n_pad/4, n_pad = N_local rounded
+//          up to 4096 (one 256-thread block = 4 wave tiles of 1024 individuals).
+//          PLINK 2-bit codes as on disk (src/data.cpp:1189-1200): 00 -> 2,
+//          10 -> 1, 11 -> 0, 01 -> missing.  Padding slots hold 01 (missing),
+//          so they contribute to no sum and receive no update.
+//   eps    2 x n_pad doubles (double-buffered: a launch that applies a pending
+//          update reads buffer `cur` and writes `cur^1`), stored PERMUTED so
+//          that the lane that holds column dword l of a wave tile (individuals
+//          16l..16l+15) reads its 16 residuals with 8 fully coalesced 16-byte
+//          loads:  slot s of lane l  ->  tile*1024 + (s>>1)*128 + l*2 + (s&1).
+//   beta/components/acum  M-sized, replicated on every rank.
+//
+// Kernels
+//   k_sweep_batch   the hot kernel.  One launch = [apply the pending
+//                   eps update of the previous launch's last marker] + [masked
+//                   sums S1,S2,SM of the next B markers in the shuffled order,
+//                   speculatively, against the same eps] + [the last-arriving
+//                   workgroup reduces the per-block partials in fixed order,
+//                   evaluates the mixture posterior of all B markers in
+//                   parallel, then consumes the shared MT19937 stream in marker
+//                   order and accepts markers up to and including the first one
+//                   whose effect changes (deltaBeta != 0) -- later dots are
+//                   stale and are recomputed by the next launch].  Exactly the
+//                   sequential chain: every accepted marker saw the eps the
+//                   reference's marker loop would have given it
+//                   (src/BayesRRm.cpp:1709-2025).
+//   k_* helpers     stats, permuted get/set, scalar add, reductions, synthetic
+//                   genotypes, single-marker dot/update.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hg_rng.h"
+
+namespace hg {
+
+constexpr int WAVE = 64;
+constexpr int IPT = 16;                  // individuals per lane per tile (one column dword)
+constexpr int TILE = WAVE * IPT;         // 1024 individuals per wave tile
+constexpr int BLOCK_WAVES = 4;
+constexpr int BLOCK = WAVE * BLOCK_WAVES;       // 256 threads
+constexpr int BLOCK_IND = TILE * BLOCK_WAVES;   // 4096 individuals per block
+constexpr int MAX_BATCH = 64;            // speculative batch width upper bound (one wave walks it)
+constexpr int MAX_K = 8;                 // mixture components incl. zero
+constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
+
+struct SweepDesc {
+    uint32_t cursor;       // next position in order[]
+    int32_t pend_marker;   // marker whose eps update is still to be applied, -1 none
+    double pv[3];          // update constants for genotype 0,1,2 (missing gets 0)
+    uint32_t cur;          // which eps buffer is current
+    uint32_t batch;        // width of the next speculative batch
+    uint32_t rng_idx;      // MT19937 position (0..624)
+    uint32_t error;        // non-zero: logL overflow abort (src/BayesRRm.cpp:1910-1913) or rng buffer overrun
+    uint64_t nnz;          // markers with deltaBeta != 0 so far
+    uint64_t launches;     // launches that did work
+    uint64_t accepted_sum; // total accepted markers (== cursor at the end)
+};
+
+struct SweepParams {
+    // data
+    const uint8_t* bed;
+    uint64_t stride;       // bytes per column
+    double* eps0;
+    double* eps1;
+    uint32_t n_pad;        // padded local individuals
+    uint32_t M;
+    double n_minus_1;      // (double)(N_global - 1)
+    const double* mave;
+    const double* mstd;
+    const int32_t* groups;
+    const int32_t* order;
+    const uint8_t* adaV;
+    // effects
+    double* beta;
+    int32_t* comp;
+    double* acum;
+    int32_t* cass;         // G*K counters
+    // hyper tables, G*K each (column 0 of denom/h/sd unused)
+    int K;
+    const double* denom;   // (N-1) + sigmaE/sigmaG[g]*cVaI[g,k]
+    const double* logpi;   // log(estPi[g,k])
+    const double* hlog;    // 0.5*log(sigmaG[g]/sigmaE*(N-1)*cVa[g,k] + 1)
+    const double* sdk;     // sqrt(sigmaE/denom[g,k])
+    double i_2sigE;        // 1/(2 sigmaE)
+    // rng
+    uint32_t* mt;          // 624 words
+    ZigTables zig;
+    // hand-off
+    SweepDesc* desc;
+    double* partials;      // [(3*MAX_BATCH + 1)][nblk_x], written sc1
+    uint32_t* ticket;
+    uint32_t nblk_x;
+    uint32_t cols_per_group; // columns handled per blockIdx.y
+    // multi-GPU: when non-null the kernel stops after the local reduction and
+    // leaves sums[3*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
+    double* sums_out;
+};
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double mask_f64(double e, int m /* 0 or -1 */)
+{
+    long long b = __double_as_longlong(e);
+    b &= (long long)m; // sign-extended 0 / all-ones
+    return __longlong_as_double(b);
+}
+
+// position of (tile-local lane l, slot s) in the permuted eps layout
+__device__ __host__ __forceinline__ uint32_t eps_pos(uint32_t i)
+{
+    uint32_t tile = i >> 10, r = i & 1023u;
+    uint32_t l = r >> 4, s = r & 15u;
+    return (tile << 10) + ((s >> 1) << 7) + (l << 1) + (s & 1u);
+}
+
+// Load the 16 residuals of this lane for wave tile `tile` (permuted layout).
+__device__ __forceinline__ void load_eps16(const double* __restrict__ eps, uint32_t tile, int lane, double (&e)[IPT])
+{
+    const double2* p = reinterpret_cast<const double2*>(eps + ((size_t)tile << 10)) + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double2 v = p[k * 64];
+        e[2 * k] = v.x;
+        e[2 * k + 1] = v.y;
+    }
+}
+
+__device__ __forceinline__ void store_eps16(double* __restrict__ eps, uint32_t tile, int lane, const double (&e)[IPT])
+{
+    double2* p = reinterpret_cast<double2*>(eps + ((size_t)tile << 10)) + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k * 64] = make_double2(e[2 * k], e[2 * k + 1]);
+}
+
+// bit-plane masks of one column dword (16 codes): bit 2s set iff code s is ...
+__device__ __forceinline__ void code_masks(uint32_t w, uint32_t& m1, uint32_t& m2, uint32_t& mm)
+{
+    uint32_t hi = w >> 1, lo = w;
+    m1 = hi & ~lo & 0x55555555u;   // code 10 -> genotype 1
+    m2 = ~hi & ~lo & 0x55555555u;  // code 00 -> genotype 2
+    mm = ~hi & lo & 0x55555555u;   // code 01 -> missing
+}
+
+// a8 on registers: eps_s += {v0,v1,v2,0}[g_s]
+__device__ __forceinline__ void apply_update16(uint32_t w, double v0, double v1, double v2, double (&e)[IPT])
+{
+#pragma unroll
+    for (int s = 0; s < IPT; ++s) {
+        uint32_t c = (w >> (2 * s)) & 3u;
+        double v = (c == 3u) ? v0 : ((c == 2u) ? v1 : ((c == 0u) ? v2 : 0.0));
+        e[s] = e[s] + (0.0 + v);
+    }
+}
+
+} // namespace hg

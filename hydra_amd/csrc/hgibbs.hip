@@ -1,0 +1,922 @@
+// hgibbs.hip -- device operators behind include/hgibbs.h (layer 1 of the C ABI).
+// Written for gfx950 only.  See hg_kernels.h for the data layout and kernels.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hgibbs.h"
+#include "hg_kernels.h"
+#include "hg_sweep.hip.h"
+
+using namespace hg;
+
+// ---------------------------------------------------------------------------
+// error plumbing (fail-stop, like check_mpi/check_malloc src/mpi_utils.hpp:19-36)
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) return fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+extern "C" void hgibbs_set_error_(const char* msg) { g_err = msg; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct hgibbs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // sharding
+    int nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+
+    // data
+    uint32_t n_global = 0, n_local = 0, n_pad = 0, M = 0, row_begin = 0;
+    uint64_t stride = 0;
+    uint8_t* bed = nullptr;
+    double* eps[2] = {nullptr, nullptr};
+    uint32_t eps_cur = 0;
+    double *mave = nullptr, *mstd = nullptr;
+    unsigned long long* counts = nullptr; // 3*M: n1, n2, nmiss (global after all-reduce)
+    bool have_stats = false;
+
+    // model / effects
+    int G = 0, K = 0;
+    int32_t* groups = nullptr;
+    std::vector<int32_t> groups_host;
+    std::vector<double> cVa, cVaI;
+    double* beta = nullptr;
+    int32_t* comp = nullptr;
+    double* acum = nullptr;
+
+    // sweep scratch
+    int32_t* order = nullptr;
+    uint8_t* adaV = nullptr;
+    int32_t* cass = nullptr;
+    double* tables = nullptr; // 4 * G*K
+    uint32_t* mt = nullptr;
+    double* zig = nullptr; // 129+129+257+257
+    SweepDesc* desc = nullptr;
+    SweepDesc* desc_host = nullptr; // pinned
+    double* partials = nullptr;
+    uint32_t* ticket = nullptr;
+    double* sums = nullptr;    // 3*MAX_BATCH+1 (multi-GPU exchange buffer)
+    double* scratch = nullptr; // reductions
+    size_t scratch_n = 0;
+    double* scratch_host = nullptr; // pinned, 4096 doubles
+    double* beta_host = nullptr;    // pinned, M doubles (lazy)
+
+    // options
+    uint32_t batch = 32;
+    uint32_t cols_per_group = 8;
+    int chunk = 0; // launches per host check (0 = adaptive)
+
+    hgibbs_sweep_stats stats{};
+};
+
+static int ensure_scratch(hgibbs_ctx* h, size_t n)
+{
+    if (h->scratch_n >= n) return 0;
+    if (h->scratch) HIP_TRY(hipFree(h->scratch));
+    HIP_TRY(hipMalloc(&h->scratch, n * sizeof(double)));
+    h->scratch_n = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// helper kernels
+// ---------------------------------------------------------------------------
+namespace {
+
+// counter-based hash for synthetic genotypes (splitmix64 finaliser)
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// One thread per byte (4 individuals) of a column.  Global row index decides
+// the draw, so any sharding reproduces the same matrix.
+__global__ void k_synth_bed(uint8_t* bed, uint64_t stride, uint32_t n_local, uint32_t row_begin, uint32_t marker0,
+                            uint64_t seed, uint32_t miss_thr)
+{
+    const uint32_t marker = marker0 + blockIdx.y;
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= stride) return;
+    // allele frequency p_j ~ U(0.01, 0.5); integer thresholds on a 32-bit uniform
+    const uint32_t up = (uint32_t)(mix64(seed ^ (0xA5A5A5A5ull + (uint64_t)marker * 0x100000001b3ull)) >> 32);
+    const double p = 0.01 + 0.49 * ((double)up * (1.0 / 4294967296.0));
+    const double q0 = (1.0 - p) * (1.0 - p);
+    const double q1 = q0 + 2.0 * p * (1.0 - p);
+    const uint32_t t0 = (uint32_t)(q0 * 4294967296.0);
+    const uint32_t t1 = (uint32_t)(q1 * 4294967296.0);
+    uint32_t byte = 0;
+    for (int s = 0; s < 4; ++s) {
+        const uint64_t il = b * 4 + s;
+        uint32_t code = 1u; // missing (padding)
+        if (il < n_local) {
+            const uint64_t ig = (uint64_t)row_begin + il;
+            const uint64_t hsh = mix64(seed + (uint64_t)marker * 0x9E3779B1ull + ig * 0xD1B54A32D192ED03ull);
+            const uint32_t ug = (uint32_t)(hsh >> 32), um = (uint32_t)hsh;
+            if (um < miss_thr) code = 1u;
+            else code = (ug < t0) ? 3u : ((ug < t1) ? 2u : 0u); // genotype 0 / 1 / 2
+        }
+        byte |= code << (2 * s);
+    }
+    bed[(uint64_t)marker * stride + b] = (uint8_t)byte;
+}
+
+// Set every 2-bit slot at local index >= n_local to the missing code.
+__global__ void k_fix_padding(uint8_t* bed, uint64_t stride, uint32_t n_local, uint32_t M)
+{
+    const uint32_t marker = blockIdx.x * blockDim.x + threadIdx.x;
+    if (marker >= M) return;
+    const uint32_t bfirst = n_local >> 2;
+    if ((n_local & 3u) && bfirst < stride) {
+        uint8_t v = bed[(uint64_t)marker * stride + bfirst];
+        for (uint32_t s = n_local & 3u; s < 4; ++s) v = (uint8_t)((v & ~(3u << (2 * s))) | (1u << (2 * s)));
+        bed[(uint64_t)marker * stride + bfirst] = v;
+    }
+}
+
+// NA-phenotype row removal: gather the kept 2-bit fields of a full column into
+// the local packed column.  src_idx[i] = source individual of local slot i.
+__global__ void k_compact_bed(const uint8_t* __restrict__ src, uint64_t src_stride, const uint32_t* __restrict__ src_idx,
+                              uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t n_local, uint32_t mcount)
+{
+    const uint32_t marker = blockIdx.y;
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= dst_stride || marker >= mcount) return;
+    uint32_t byte = 0;
+    for (int s = 0; s < 4; ++s) {
+        const uint64_t il = b * 4 + s;
+        uint32_t code = 1u;
+        if (il < n_local) {
+            const uint32_t i = src_idx[il];
+            code = (src[(uint64_t)marker * src_stride + (i >> 2)] >> (2 * (i & 3u))) & 3u;
+        }
+        byte |= code << (2 * s);
+    }
+    dst[(uint64_t)marker * dst_stride + b] = (uint8_t)byte;
+}
+
+// per-marker genotype counts over the local shard: one block per marker
+__global__ __launch_bounds__(BLOCK) void k_counts(const uint8_t* __restrict__ bed, uint64_t stride, uint32_t n_pad,
+                                                  uint32_t n_local, unsigned long long* __restrict__ counts, uint32_t M)
+{
+    __shared__ unsigned int sh[3][BLOCK_WAVES];
+    const uint32_t marker = blockIdx.x;
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(bed + (uint64_t)marker * stride);
+    const uint32_t nw = (uint32_t)(stride >> 2);
+    unsigned int c1 = 0, c2 = 0, cm = 0;
+    for (uint32_t i = threadIdx.x; i < nw; i += BLOCK) {
+        uint32_t m1, m2, mm;
+        code_masks(col[i], m1, m2, mm);
+        c1 += __popc(m1);
+        c2 += __popc(m2);
+        cm += __popc(mm);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        c1 += __shfl_xor(c1, off, 64);
+        c2 += __shfl_xor(c2, off, 64);
+        cm += __shfl_xor(cm, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = c1;
+        sh[1][wave] = c2;
+        sh[2][wave] = cm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t1 = 0, t2 = 0, tm = 0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) {
+            t1 += sh[0][w];
+            t2 += sh[1][w];
+            tm += sh[2][w];
+        }
+        counts[3ull * marker] = t1;
+        counts[3ull * marker + 1] = t2;
+        counts[3ull * marker + 2] = tm - (unsigned long long)(n_pad - n_local); // padding slots are coded missing
+    }
+}
+
+// a2: src/BayesRRm.cpp:1502-1507 from the (global) counts
+__global__ void k_stats(const unsigned long long* __restrict__ counts, uint32_t N, double* mave, double* mstd, uint32_t M)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double n1 = (double)counts[3ull * i], n2 = (double)counts[3ull * i + 1], nm = (double)counts[3ull * i + 2];
+    const double dN = (double)N;
+    const double av = (n1 + 2.0 * n2) / (dN - nm);
+    const double tmp1 = n1 * (1.0 - av) * (1.0 - av);
+    const double tmp2 = n2 * (2.0 - av) * (2.0 - av);
+    const unsigned long long n0 = (unsigned long long)N - counts[3ull * i] - counts[3ull * i + 1] - counts[3ull * i + 2];
+    const double tmp0 = (double)n0 * (0.0 - av) * (0.0 - av);
+    mave[i] = av;
+    mstd[i] = sqrt((double)(N - 1) / (tmp0 + tmp1 + tmp2));
+}
+
+__global__ void k_set_eps(double* eps, const double* __restrict__ src, uint32_t n_local, uint32_t n_pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    eps[eps_pos(i)] = (i < n_local) ? src[i] : 0.0;
+}
+
+__global__ void k_get_eps(const double* __restrict__ eps, double* dst, uint32_t n_local)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local) return;
+    dst[i] = eps[eps_pos(i)];
+}
+
+// eps_i += c for real individuals only (padding stays 0)
+__global__ void k_add_scalar(double* eps, double c, uint32_t n_local, uint32_t n_pad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local) return;
+    const uint32_t p = eps_pos(i);
+    eps[p] = eps[p] + c;
+}
+
+// per-block partial (sum, sqn) in natural individual order inside the block
+__global__ __launch_bounds__(BLOCK) void k_reduce_eps(const double* __restrict__ eps, uint32_t n_pad, double* partial)
+{
+    __shared__ double sh[2][BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT];
+    load_eps16(eps, tile, lane, e);
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        s += e[i];
+        q += e[i] * e[i];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        sh[0][wave] = s;
+        sh[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tq = 0.0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) {
+            ts += sh[0][w];
+            tq += sh[1][w];
+        }
+        partial[2 * blockIdx.x] = ts;
+        partial[2 * blockIdx.x + 1] = tq;
+    }
+}
+
+// fixed-order final reduction of `rows` interleaved partial rows: out[r] = sum_b partial[b*rows + r]
+__global__ __launch_bounds__(BLOCK) void k_final_sum(const double* __restrict__ partial, uint32_t nblk, uint32_t rows, double* out)
+{
+    __shared__ double sh[BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t r = 0; r < rows; ++r) {
+        double v = 0.0;
+        for (uint32_t b = threadIdx.x; b < nblk; b += BLOCK) v += partial[(size_t)b * rows + r];
+        v = wave_sum(v);
+        if (lane == 0) sh[wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < BLOCK_WAVES; ++w) t += sh[w];
+            out[r] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// single-marker masked sums (S1,S2,SM,Sall) per block -> partial[b*4 + {0..3}]
+__global__ __launch_bounds__(BLOCK) void k_dot_one(const uint8_t* __restrict__ bed, uint64_t stride, uint32_t marker,
+                                                   const double* __restrict__ eps, double* partial)
+{
+    __shared__ double sh[4][BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT];
+    load_eps16(eps, tile, lane, e);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(bed + (size_t)marker * stride + ((size_t)tile << 8) + (lane << 2));
+    uint32_t m1, m2, mm;
+    code_masks(w, m1, m2, mm);
+    double s1 = 0.0, s2 = 0.0, sm = 0.0, sa = 0.0;
+#pragma unroll
+    for (int s = 0; s < IPT; ++s) {
+        s1 += mask_f64(e[s], ((int)(m1 << (31 - 2 * s))) >> 31);
+        s2 += mask_f64(e[s], ((int)(m2 << (31 - 2 * s))) >> 31);
+        sm += mask_f64(e[s], ((int)(mm << (31 - 2 * s))) >> 31);
+        sa += e[s];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    sm = wave_sum(sm);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+        sh[0][wave] = s1;
+        sh[1][wave] = s2;
+        sh[2][wave] = sm;
+        sh[3][wave] = sa;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int wv = 0; wv < BLOCK_WAVES; ++wv) t += sh[threadIdx.x][wv];
+        partial[4 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_update_one(const uint8_t* __restrict__ bed, uint64_t stride, uint32_t marker,
+                                                      double* eps, double v0, double v1, double v2)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT];
+    load_eps16(eps, tile, lane, e);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(bed + (size_t)marker * stride + ((size_t)tile << 8) + (lane << 2));
+    apply_update16(w, v0, v1, v2, e);
+    store_eps16(eps, tile, lane, e);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* hgibbs_last_error(void) { return g_err.c_str(); }
+int hgibbs_version(void) { return 1; }
+
+int hgibbs_create(int device_id, hgibbs_t* out)
+{
+    if (!out) return fail("hgibbs_create: null out");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("hgibbs_create: no HIP device (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail("hgibbs_create: device %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("hgibbs_create: device %d is %s, this library is built for gfx950 only", device_id, prop.gcnArchName);
+    hgibbs_ctx* h = new hgibbs_ctx();
+    h->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipMalloc(&h->mt, MT_N * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->zig, (129 + 129 + 257 + 257) * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->zig, HG_ZIG_NORMAL_X, 129 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->zig + 129, HG_ZIG_NORMAL_Y, 129 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->zig + 258, HG_ZIG_EXP_X, 257 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->zig + 515, HG_ZIG_EXP_Y, 257 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc)));
+    HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
+    HIP_TRY(hipMalloc(&h->ticket, 64));
+    HIP_TRY(hipMemset(h->ticket, 0, 64));
+    HIP_TRY(hipMalloc(&h->sums, (3 * MAX_BATCH + 1) * sizeof(double)));
+    HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
+    *out = h;
+    return 0;
+}
+
+int hgibbs_destroy(hgibbs_t h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy(h->comm);
+    void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
+                    h->adaV, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->desc_host) (void)hipHostFree(h->desc_host);
+    if (h->scratch_host) (void)hipHostFree(h->scratch_host);
+    if (h->beta_host) (void)hipHostFree(h->beta_host);
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int hgibbs_comm_unique_id(void* id128)
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int hgibbs_comm_init(hgibbs_t h, int nranks, int rank, const void* id128)
+{
+    if (!h) return fail("null handle");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("hgibbs_comm_init: bad rank %d of %d", rank, nranks);
+    h->nranks = nranks;
+    h->rank = rank;
+    if (nranks == 1) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCL_TRY(ncclCommInitRank(&h->comm, nranks, id, rank));
+    return 0;
+}
+
+static int alloc_problem(hgibbs_ctx* h, uint32_t n_global, uint32_t n_local, uint32_t M, uint32_t row_begin)
+{
+    if (n_local == 0 || M == 0) return fail("empty problem: n_local=%u M=%u", n_local, M);
+    if (h->bed) return fail("data already loaded on this handle");
+    h->n_global = n_global;
+    h->n_local = n_local;
+    h->M = M;
+    h->row_begin = row_begin;
+    h->n_pad = (uint32_t)(((uint64_t)n_local + BLOCK_IND - 1) / BLOCK_IND * BLOCK_IND);
+    h->stride = h->n_pad / 4;
+    HIP_TRY(hipMalloc(&h->bed, (size_t)M * h->stride));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMalloc(&h->eps[b], (size_t)h->n_pad * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(h->eps[b], 0, (size_t)h->n_pad * sizeof(double), h->stream));
+    }
+    HIP_TRY(hipMalloc(&h->mave, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->mstd, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->counts, (size_t)M * 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->beta, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->comp, (size_t)M * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->acum, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->order, (size_t)M * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->adaV, (size_t)M));
+    HIP_TRY(hipMalloc(&h->groups, (size_t)M * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->beta, 0, (size_t)M * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->comp, 0, (size_t)M * sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->acum, 0, (size_t)M * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->groups, 0, (size_t)M * sizeof(int32_t), h->stream));
+    const uint32_t nblk_x = h->n_pad / BLOCK_IND;
+    HIP_TRY(hipMalloc(&h->partials, (size_t)(3 * MAX_BATCH + 1) * nblk_x * sizeof(double)));
+    if (ensure_scratch(h, (size_t)nblk_x * 4 + 4096)) return 1;
+    h->eps_cur = 0;
+    h->have_stats = false;
+    return 0;
+}
+
+int hgibbs_load_bed(hgibbs_t h, const uint8_t* bed_host, uint64_t stride_in, uint32_t n_total, uint32_t M,
+                    const uint8_t* keep_host, uint32_t row_begin, uint32_t row_end, uint32_t n_global)
+{
+    if (!h || !bed_host) return fail("hgibbs_load_bed: null argument");
+    if (row_end <= row_begin) return fail("hgibbs_load_bed: empty row range");
+    if (stride_in < ((uint64_t)n_total + 3) / 4) return fail("hgibbs_load_bed: stride_in %llu < ceil(%u/4)", (unsigned long long)stride_in, n_total);
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t n_local = row_end - row_begin;
+    if (alloc_problem(h, n_global, n_local, M, row_begin)) return 1;
+    HIP_TRY(hipMemsetAsync(h->bed, 0x55, (size_t)M * h->stride, h->stream));
+
+    if (!keep_host) {
+        if (row_end > n_total) return fail("hgibbs_load_bed: row_end %u > n_total %u", row_end, n_total);
+        if (row_begin & 3u) return fail("hgibbs_load_bed: row_begin %u must be a multiple of 4", row_begin);
+        const size_t width = ((size_t)n_local + 3) / 4;
+        HIP_TRY(hipMemcpy2DAsync(h->bed, h->stride, bed_host + (row_begin >> 2), stride_in, width, M, hipMemcpyHostToDevice, h->stream));
+        k_fix_padding<<<(M + 255) / 256, 256, 0, h->stream>>>(h->bed, h->stride, n_local, M);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // NA rows dropped: build the kept-row index list, then gather on the device in slabs of columns
+        std::vector<uint32_t> kept;
+        kept.reserve(n_total);
+        for (uint32_t i = 0; i < n_total; ++i)
+            if (keep_host[i]) kept.push_back(i);
+        if (row_end > kept.size()) return fail("hgibbs_load_bed: row_end %u > kept individuals %zu", row_end, kept.size());
+        uint32_t* d_idx = nullptr;
+        HIP_TRY(hipMalloc(&d_idx, (size_t)n_local * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(d_idx, kept.data() + row_begin, (size_t)n_local * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        const uint32_t slab = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(M, (256ull << 20) / std::max<uint64_t>(1, stride_in)));
+        uint8_t* d_src = nullptr;
+        HIP_TRY(hipMalloc(&d_src, (size_t)slab * stride_in));
+        for (uint32_t m0 = 0; m0 < M; m0 += slab) {
+            const uint32_t mc = std::min(slab, M - m0);
+            HIP_TRY(hipMemcpyAsync(d_src, bed_host + (size_t)m0 * stride_in, (size_t)mc * stride_in, hipMemcpyHostToDevice, h->stream));
+            dim3 grid((uint32_t)((h->stride + 255) / 256), mc);
+            k_compact_bed<<<grid, 256, 0, h->stream>>>(d_src, stride_in, d_idx, h->bed + (size_t)m0 * h->stride, h->stride, n_local, mc);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(d_src));
+        HIP_TRY(hipFree(d_idx));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hgibbs_synth_bed(hgibbs_t h, uint32_t n_global, uint32_t M, uint32_t row_begin, uint32_t row_end, uint64_t seed,
+                     double missing_rate)
+{
+    if (!h) return fail("null handle");
+    if (row_end <= row_begin || row_end > n_global) return fail("hgibbs_synth_bed: bad row range");
+    HIP_TRY(hipSetDevice(h->device));
+    if (alloc_problem(h, n_global, row_end - row_begin, M, row_begin)) return 1;
+    double mr = missing_rate < 0 ? 0 : (missing_rate > 1 ? 1 : missing_rate);
+    const uint32_t miss_thr = (uint32_t)std::min(4294967295.0, mr * 4294967296.0);
+    // grid.y is limited to 65535: synthesise in slabs of markers
+    for (uint32_t m0 = 0; m0 < M; m0 += 32768) {
+        const uint32_t mc = std::min<uint32_t>(32768, M - m0);
+        dim3 grid((uint32_t)((h->stride + 255) / 256), mc);
+        k_synth_bed<<<grid, 256, 0, h->stream>>>(h->bed, h->stride, h->n_local, row_begin, m0, seed, miss_thr);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int hgibbs_dims(hgibbs_t h, uint32_t* n_global, uint32_t* n_local, uint32_t* M, uint32_t* row_begin)
+{
+    if (!h) return fail("hgibbs_dims: null handle");
+    if (n_global) *n_global = h->n_global;
+    if (n_local) *n_local = h->n_local;
+    if (M) *M = h->M;
+    if (row_begin) *row_begin = h->row_begin;
+    return 0;
+}
+
+int hgibbs_get_bed(hgibbs_t h, uint32_t m0, uint32_t mcount, uint8_t* out_host, uint64_t out_stride)
+{
+    if (!h || !h->bed) return fail("hgibbs_get_bed: no data");
+    if ((uint64_t)m0 + mcount > h->M) return fail("hgibbs_get_bed: marker range out of bounds");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t width = ((size_t)h->n_local + 3) / 4;
+    if (out_stride < width) return fail("hgibbs_get_bed: out_stride too small");
+    HIP_TRY(hipMemcpy2D(out_host, out_stride, h->bed + (size_t)m0 * h->stride, h->stride, width, mcount, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int compute_stats(hgibbs_ctx* h)
+{
+    if (h->have_stats) return 0;
+    k_counts<<<h->M, BLOCK, 0, h->stream>>>(h->bed, h->stride, h->n_pad, h->n_local, h->counts, h->M);
+    HIP_TRY(hipGetLastError());
+    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->counts, h->counts, (size_t)h->M * 3, ncclUint64, ncclSum, h->comm, h->stream));
+    k_stats<<<(h->M + 255) / 256, 256, 0, h->stream>>>(h->counts, h->n_global, h->mave, h->mstd, h->M);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_stats = true;
+    return 0;
+}
+
+int hgibbs_marker_stats(hgibbs_t h, double* mave_host, double* mstd_host, uint64_t* n1_host, uint64_t* n2_host, uint64_t* nmiss_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_marker_stats: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    if (compute_stats(h)) return 1;
+    if (mave_host) HIP_TRY(hipMemcpy(mave_host, h->mave, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (mstd_host) HIP_TRY(hipMemcpy(mstd_host, h->mstd, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (n1_host || n2_host || nmiss_host) {
+        std::vector<unsigned long long> c((size_t)h->M * 3);
+        HIP_TRY(hipMemcpy(c.data(), h->counts, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < h->M; ++i) {
+            if (n1_host) n1_host[i] = c[3ull * i];
+            if (n2_host) n2_host[i] = c[3ull * i + 1];
+            if (nmiss_host) nmiss_host[i] = c[3ull * i + 2];
+        }
+    }
+    return 0;
+}
+
+int hgibbs_set_residual(hgibbs_t h, const double* eps_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_set_residual: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    double* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)h->n_local * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(tmp, eps_host, (size_t)h->n_local * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    k_set_eps<<<(h->n_pad + 255) / 256, 256, 0, h->stream>>>(h->eps[h->eps_cur], tmp, h->n_local, h->n_pad);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(tmp));
+    return 0;
+}
+
+int hgibbs_get_residual(hgibbs_t h, double* eps_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_get_residual: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    double* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)h->n_local * sizeof(double)));
+    k_get_eps<<<(h->n_local + 255) / 256, 256, 0, h->stream>>>(h->eps[h->eps_cur], tmp, h->n_local);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(eps_host, tmp, (size_t)h->n_local * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(tmp));
+    return 0;
+}
+
+int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
+{
+    if (!h || !h->bed) return fail("hgibbs_reduce_eps: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblk = h->n_pad / BLOCK_IND;
+    k_reduce_eps<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], h->n_pad, h->scratch);
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 2, h->sums);
+    HIP_TRY(hipGetLastError());
+    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 2, ncclDouble, ncclSum, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (sum) *sum = h->scratch_host[0];
+    if (sqn) *sqn = h->scratch_host[1];
+    return 0;
+}
+
+int hgibbs_add_scalar(hgibbs_t h, double c)
+{
+    if (!h || !h->bed) return fail("hgibbs_add_scalar: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    k_add_scalar<<<(h->n_local + 255) / 256, 256, 0, h->stream>>>(h->eps[h->eps_cur], c, h->n_local, h->n_pad);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hgibbs_update_marker(hgibbs_t h, uint32_t marker, double dbeta)
+{
+    if (!h || !h->bed) return fail("hgibbs_update_marker: no data loaded");
+    if (marker >= h->M) return fail("hgibbs_update_marker: marker %u >= M %u", marker, h->M);
+    HIP_TRY(hipSetDevice(h->device));
+    if (compute_stats(h)) return 1;
+    if (dbeta == 0.0) return 0;
+    double ms[2];
+    HIP_TRY(hipMemcpy(&ms[0], h->mave + marker, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&ms[1], h->mstd + marker, sizeof(double), hipMemcpyDeviceToHost));
+    const double v0 = -(ms[0] * ms[1] * dbeta);
+    const double v1 = dbeta * (1.0 - ms[0]) * ms[1];
+    const double v2 = dbeta * (2.0 - ms[0]) * ms[1];
+    k_update_one<<<h->n_pad / BLOCK_IND, BLOCK, 0, h->stream>>>(h->bed, h->stride, marker, h->eps[h->eps_cur], v0, v1, v2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num)
+{
+    if (!h || !h->bed || !num) return fail("hgibbs_dot_marker: bad argument");
+    if (marker >= h->M) return fail("hgibbs_dot_marker: marker %u >= M %u", marker, h->M);
+    HIP_TRY(hipSetDevice(h->device));
+    if (compute_stats(h)) return 1;
+    const uint32_t nblk = h->n_pad / BLOCK_IND;
+    k_dot_one<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, marker, h->eps[h->eps_cur], h->scratch);
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 4, h->sums);
+    HIP_TRY(hipGetLastError());
+    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 4, ncclDouble, ncclSum, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->scratch_host + 4, h->mave + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->scratch_host + 5, h->mstd + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double S1 = h->scratch_host[0], S2 = h->scratch_host[1], SM = h->scratch_host[2], Sall = h->scratch_host[3];
+    double dp = 0.0;
+    dp += S1 * 1.0;
+    dp += S2 * 2.0;
+    double syt = Sall;
+    syt -= SM;
+    dp -= (h->scratch_host[4] * syt);
+    dp *= h->scratch_host[5];
+    *num = dp;
+    return 0;
+}
+
+int hgibbs_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const double* cVa_host, const double* cVaI_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_set_model: load data first");
+    if (G < 1 || K < 2 || K > MAX_K) return fail("hgibbs_set_model: need G>=1 and 2<=K<=%d (got G=%d K=%d)", MAX_K, G, K);
+    HIP_TRY(hipSetDevice(h->device));
+    h->G = G;
+    h->K = K;
+    h->groups_host.assign(h->M, 0);
+    if (groups_host) {
+        for (uint32_t i = 0; i < h->M; ++i) {
+            if (groups_host[i] < 0 || groups_host[i] >= G) return fail("hgibbs_set_model: groups[%u]=%d outside [0,%d)", i, groups_host[i], G);
+            h->groups_host[i] = groups_host[i];
+        }
+    }
+    HIP_TRY(hipMemcpy(h->groups, h->groups_host.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->cVa.assign(cVa_host, cVa_host + (size_t)G * K);
+    h->cVaI.assign(cVaI_host, cVaI_host + (size_t)G * K);
+    if (h->cass) HIP_TRY(hipFree(h->cass));
+    if (h->tables) HIP_TRY(hipFree(h->tables));
+    HIP_TRY(hipMalloc(&h->cass, (size_t)G * K * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->tables, (size_t)4 * G * K * sizeof(double)));
+    return 0;
+}
+
+int hgibbs_set_beta(hgibbs_t h, const double* beta_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_set_beta: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->beta, beta_host, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int hgibbs_get_beta(hgibbs_t h, double* beta_host, int32_t* components_host, double* acum_host)
+{
+    if (!h || !h->bed) return fail("hgibbs_get_beta: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (beta_host) HIP_TRY(hipMemcpy(beta_host, h->beta, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (components_host) HIP_TRY(hipMemcpy(components_host, h->comp, (size_t)h->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (acum_host) HIP_TRY(hipMemcpy(acum_host, h->acum, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hgibbs_beta_sqnorm(hgibbs_t h, double* bsq_host)
+{
+    if (!h || !h->bed || h->G < 1) return fail("hgibbs_beta_sqnorm: model not set");
+    HIP_TRY(hipSetDevice(h->device));
+    // M doubles cross PCIe once per iteration (they are needed on the host for
+    // the .bet output anyway); the sum then runs sequentially in marker order,
+    // exactly as src/BayesRRm.cpp:2496-2499.
+    if (!h->beta_host) HIP_TRY(hipHostMalloc(&h->beta_host, (size_t)h->M * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(h->beta_host, h->beta, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int g = 0; g < h->G; ++g) bsq_host[g] = 0.0;
+    for (uint32_t i = 0; i < h->M; ++i) bsq_host[h->groups_host[i]] += h->beta_host[i] * h->beta_host[i];
+    return 0;
+}
+
+int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
+{
+    if (!h || !name) return fail("hgibbs_set_option: null argument");
+    if (!std::strcmp(name, "batch")) {
+        if (value < 1 || value > MAX_BATCH) return fail("batch must be in [1,%d]", MAX_BATCH);
+        h->batch = (uint32_t)value;
+    } else if (!std::strcmp(name, "cols_per_group")) {
+        if (value < 1 || value > MAX_BATCH) return fail("cols_per_group must be in [1,%d]", MAX_BATCH);
+        h->cols_per_group = (uint32_t)value;
+    } else if (!std::strcmp(name, "chunk")) {
+        h->chunk = (int)value;
+    } else {
+        return fail("hgibbs_set_option: unknown option '%s'", name);
+    }
+    return 0;
+}
+
+int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out)
+{
+    if (!h || !out) return fail("null argument");
+    *out = h->stats;
+    return 0;
+}
+
+int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const double* sigmaG_host, const double* estPi_host,
+                 const uint8_t* adaV_host, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
+{
+    if (!h || !h->bed) return fail("hgibbs_sweep: no data loaded");
+    if (h->G < 1) return fail("hgibbs_sweep: model not set");
+    if (!order_host || !sigmaG_host || !estPi_host || !adaV_host || !rng) return fail("hgibbs_sweep: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (compute_stats(h)) return 1;
+    const int G = h->G, K = h->K;
+    const uint32_t M = h->M;
+    for (uint32_t i = 0; i < M; ++i)
+        if (order_host[i] < 0 || (uint32_t)order_host[i] >= M) return fail("hgibbs_sweep: order[%u]=%d outside [0,%u)", i, order_host[i], M);
+    if (rng->idx > (uint32_t)MT_N) return fail("hgibbs_sweep: rng idx %u > 624", rng->idx);
+
+    // per-sweep hyper tables (the marker-independent factors of src/BayesRRm.cpp:1721-1723,1750,1875,1901)
+    const double dNm1 = (double)(h->n_global - 1);
+    std::vector<double> tab((size_t)4 * G * K, 0.0);
+    double* denom = tab.data();
+    double* logpi = denom + (size_t)G * K;
+    double* hlog = logpi + (size_t)G * K;
+    double* sdk = hlog + (size_t)G * K;
+    for (int g = 0; g < G; ++g) {
+        const double sigE_G = sigmaE / sigmaG_host[g];
+        const double sigG_E = sigmaG_host[g] / sigmaE;
+        for (int k = 0; k < K; ++k) {
+            logpi[g * K + k] = log(estPi_host[g * K + k]);
+            if (k >= 1) {
+                denom[g * K + k] = dNm1 + sigE_G * h->cVaI[g * K + k];
+                hlog[g * K + k] = 0.5 * log(sigG_E * dNm1 * h->cVa[g * K + k] + 1.0);
+                sdk[g * K + k] = sqrt(sigmaE / denom[g * K + k]);
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(h->tables, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->order, order_host, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->adaV, adaV_host, (size_t)M, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ticket, 0, 64, h->stream));
+
+    const uint32_t cpg = std::min(h->cols_per_group, h->batch);
+    const uint32_t ngroups = (h->batch + cpg - 1) / cpg;
+    SweepDesc d0{};
+    d0.cursor = 0;
+    d0.pend_marker = -1;
+    d0.cur = h->eps_cur;
+    d0.batch = h->batch;
+    d0.rng_idx = rng->idx;
+    *h->desc_host = d0;
+    HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream)); // staging buffers are on the host stack / pageable
+
+    SweepParams p{};
+    p.bed = h->bed;
+    p.stride = h->stride;
+    p.eps0 = h->eps[0];
+    p.eps1 = h->eps[1];
+    p.n_pad = h->n_pad;
+    p.M = M;
+    p.n_minus_1 = dNm1;
+    p.mave = h->mave;
+    p.mstd = h->mstd;
+    p.groups = h->groups;
+    p.order = h->order;
+    p.adaV = h->adaV;
+    p.beta = h->beta;
+    p.comp = h->comp;
+    p.acum = h->acum;
+    p.cass = h->cass;
+    p.K = K;
+    p.denom = h->tables;
+    p.logpi = h->tables + (size_t)G * K;
+    p.hlog = h->tables + (size_t)2 * G * K;
+    p.sdk = h->tables + (size_t)3 * G * K;
+    p.i_2sigE = 1.0 / (2.0 * sigmaE);
+    p.mt = h->mt;
+    p.zig = ZigTables{h->zig, h->zig + 129, h->zig + 258, h->zig + 515};
+    p.desc = h->desc;
+    p.partials = h->partials;
+    p.ticket = h->ticket;
+    p.nblk_x = h->n_pad / BLOCK_IND;
+    p.cols_per_group = cpg;
+    p.sums_out = (h->nranks > 1) ? h->sums : nullptr;
+
+    const dim3 grid(p.nblk_x, ngroups);
+    uint64_t total_launches = 0;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    double avg_accept = std::max(1.0, (double)h->batch * 0.5);
+    for (;;) {
+        const SweepDesc& dh = *h->desc_host;
+        const uint32_t remaining = M - std::min(M, dh.cursor);
+        int n = h->chunk > 0 ? h->chunk : (int)std::min<double>(2048.0, std::max(8.0, 1.25 * remaining / avg_accept + 2));
+        for (int i = 0; i < n; ++i) {
+            k_sweep_batch<<<grid, BLOCK, 0, h->stream>>>(p);
+            if (h->nranks > 1) {
+                NCCL_TRY(ncclAllReduce(h->sums, h->sums, 3 * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+                k_sweep_draw<<<1, BLOCK, 0, h->stream>>>(p);
+            }
+        }
+        total_launches += (uint64_t)n;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->desc_host, h->desc, sizeof(SweepDesc), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun)", dh.error, dh.cursor);
+        if (dh.launches > 0) avg_accept = std::max(1.0, (double)dh.accepted_sum / (double)dh.launches);
+        if (dh.cursor >= M && dh.pend_marker < 0) break;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+
+    h->eps_cur = h->desc_host->cur;
+    rng->idx = h->desc_host->rng_idx;
+    HIP_TRY(hipMemcpy(rng->x, h->mt, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cass_host) HIP_TRY(hipMemcpy(cass_host, h->cass, (size_t)G * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nnz_updates) *nnz_updates = h->desc_host->nnz;
+    h->stats.launches = total_launches;
+    h->stats.nnz_updates = h->desc_host->nnz;
+    h->stats.device_ms = ms;
+    h->stats.kernel_ms_avg = total_launches ? ms / (double)total_launches : 0.0;
+    return 0;
+}
+
+} // extern "C"

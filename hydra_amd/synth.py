@@ -120,3 +120,40 @@ def read_bed(path, N, M):
         raise ValueError("not a SNP-major PLINK .bed: %s" % path)
     nb = (N + 3) // 4
     return raw[3:3 + M * nb].reshape(M, nb)
+
+
+# ---- host twin of the device-side synthetic generator (hgibbs_synth_bed) ----
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def synth_bed_reference(n_global, M, seed=42, missing_rate=0.0, row_begin=0, row_end=None):
+    """Pure-Python restatement of k_synth_bed (hydra_amd/csrc/hgibbs.hip) for
+    small sizes: same counter hash, same integer thresholds."""
+    if row_end is None:
+        row_end = n_global
+    n_local = row_end - row_begin
+    mr = min(max(missing_rate, 0.0), 1.0)
+    miss_thr = int(min(4294967295.0, mr * 4294967296.0))
+    geno = np.zeros((M, n_local), dtype=np.uint8)
+    for j in range(M):
+        up = _mix64(seed ^ ((0xA5A5A5A5 + j * 0x100000001B3) & _M64)) >> 32
+        p = 0.01 + 0.49 * (float(up) * (1.0 / 4294967296.0))
+        q0 = (1.0 - p) * (1.0 - p)
+        q1 = q0 + 2.0 * p * (1.0 - p)
+        t0, t1 = int(q0 * 4294967296.0), int(q1 * 4294967296.0)
+        for il in range(n_local):
+            ig = row_begin + il
+            h = _mix64((seed + j * 0x9E3779B1 + ig * 0xD1B54A32D192ED03) & _M64)
+            ug, um = h >> 32, h & 0xFFFFFFFF
+            if um < miss_thr:
+                geno[j, il] = 3
+            else:
+                geno[j, il] = 0 if ug < t0 else (1 if ug < t1 else 2)
+    return pack_bed_columns(geno)

@@ -1,0 +1,167 @@
+/* include/hgibbs.h -- C ABI of the MI355X-native BayesRR single-site Gibbs hot path.
+ *
+ * The reference (medical-genomics-group/hydra) has no plugin/FFI boundary: the
+ * sampler is one member function, BayesRRm::runMpiGibbs (src/BayesRRm.cpp:933).
+ * This ABI cuts that function at the seam between data load (:1349) and output
+ * (:2736): everything N-sized or M-sized lives on the GPU behind an opaque
+ * handle, the host keeps only K/G-sized hyper-parameters and the RNG it shares
+ * with the device.  Two layers:
+ *
+ *   hgibbs_*   device operators -- what a maintainer would call from
+ *              runMpiGibbs in place of the CPU loops cited per entry point;
+ *   hydra_*    the host driver itself (the body of runMpiGibbs restated on top
+ *              of hgibbs_*), so that the CLI and language bindings share it.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every call
+ * returns 0 on success, non-zero on error (hgibbs_last_error() has the text;
+ * like the reference's check_mpi/check_malloc, src/mpi_utils.hpp:19-36, errors
+ * are fail-stop for the chain).  One caller thread per handle; calls on one
+ * handle are never concurrent.  The library owns all device memory; host
+ * buffers are only read/written during the call.  Arrays named *_host are host
+ * pointers; nothing in this ABI takes a device pointer.
+ */
+#ifndef HGIBBS_H
+#define HGIBBS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hgibbs_ctx* hgibbs_t;
+
+/* MT19937 state shared between host and device (boost::mt19937 of
+ * src/distributions_boost.hpp:27; host side drives std::shuffle and the
+ * hyper-parameter draws, device side the per-marker draws). */
+typedef struct {
+    uint32_t x[624];
+    uint32_t idx; /* next output position, 624 = twist first */
+} hgibbs_rng_state;
+
+const char* hgibbs_last_error(void);
+int hgibbs_version(void);
+
+/* ---- lifetime --------------------------------------------------------- */
+/* One handle per GPU (one process per GPU in multi-GPU runs). */
+int hgibbs_create(int device_id, hgibbs_t* out);
+int hgibbs_destroy(hgibbs_t h);
+
+/* ---- individuals sharded across GPUs (replaces the MPI_Allreduce family of
+ * src/BayesRRm.cpp:2051,2456,2517-2518 -- SURVEY.md 2.2) ------------------ */
+/* rank 0 fills id128 (ncclUniqueId, 128 bytes); the caller broadcasts it by
+ * whatever means it has (torch.distributed, MPI, a file) and every rank calls
+ * hgibbs_comm_init.  nranks == 1 needs neither call. */
+int hgibbs_comm_unique_id(void* id128);
+int hgibbs_comm_init(hgibbs_t h, int nranks, int rank, const void* id128);
+
+/* ---- data: replaces Data::load_data_from_bed_file + sparse index build
+ * (src/data.cpp:671-739, :1224-1290) -------------------------------------- */
+/* bed_host: SNP-major packed columns WITHOUT the 3 magic bytes, M columns of
+ * stride_in = ceil(n_total/4) bytes.  keep_host: n_total bytes, 0 drops the
+ * individual (NA phenotype, src/data.cpp:1112-1158), NULL keeps all.  Of the
+ * kept individuals this rank takes the half-open range [row_begin,row_end)
+ * (row_begin % 4 == 0 unless keep_host is given).  n_global = number of kept
+ * individuals over all ranks (the N of every formula). */
+int hgibbs_load_bed(hgibbs_t h, const uint8_t* bed_host, uint64_t stride_in, uint32_t n_total, uint32_t M,
+                    const uint8_t* keep_host, uint32_t row_begin, uint32_t row_end, uint32_t n_global);
+/* Seeded synthetic genotypes generated directly in HBM (BASELINE.md section 4:
+ * g ~ Binomial(2,p_j), p_j ~ U(0.01,0.5), missing calls at missing_rate).
+ * Row i of the global matrix depends only on (seed, marker, i), so any
+ * sharding yields the same matrix. */
+int hgibbs_synth_bed(hgibbs_t h, uint32_t n_global, uint32_t M, uint32_t row_begin, uint32_t row_end,
+                     uint64_t seed, double missing_rate);
+/* Problem sizes as loaded: N over all ranks, this rank's individuals, markers,
+ * first global row of this rank.  Any pointer may be NULL. */
+int hgibbs_dims(hgibbs_t h, uint32_t* n_global, uint32_t* n_local, uint32_t* M, uint32_t* row_begin);
+/* Copy packed columns [m0, m0+mcount) of this rank's shard back (tests). */
+int hgibbs_get_bed(hgibbs_t h, uint32_t m0, uint32_t mcount, uint8_t* out_host, uint64_t out_stride);
+
+/* a2: per-marker counts and mave/mstd (src/BayesRRm.cpp:1502-1508), counts
+ * summed over ranks.  Any output pointer may be NULL. */
+int hgibbs_marker_stats(hgibbs_t h, double* mave_host, double* mstd_host, uint64_t* n1_host, uint64_t* n2_host,
+                        uint64_t* nmiss_host);
+
+/* ---- residual: eps_host has this rank's row_end-row_begin entries -------- */
+int hgibbs_set_residual(hgibbs_t h, const double* eps_host);
+int hgibbs_get_residual(hgibbs_t h, double* eps_host);
+/* sum and squared norm over ALL ranks (src/BayesRRm.cpp:1677-1678, :2685-2686) */
+int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn);
+/* eps_i += c (src/BayesRRm.cpp:1675, :1686) */
+int hgibbs_add_scalar(hgibbs_t h, double c);
+/* eps += x_marker * (-dbeta) ... i.e. the a8 update for one marker on its own
+ * (src/BayesRRm.cpp:250-281): eps_i += {v0,v1,v2,0}[g_i] with
+ * v0=-(mave*mstd*dbeta), v1=dbeta*(1-mave)*mstd, v2=dbeta*(2-mave)*mstd. */
+int hgibbs_update_marker(hgibbs_t h, uint32_t marker, double dbeta);
+/* a4 for one marker on its own: num = x_marker' eps (before + beta*(N-1)),
+ * summed over ranks (src/BayesRRm.cpp:316-342). */
+int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num);
+
+/* ---- model (src/BayesRRm.cpp:1037-1110) --------------------------------- */
+/* groups_host[M] in [0,G); cVa/cVaI are G*K row-major with column 0 == 0. */
+int hgibbs_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const double* cVa_host,
+                     const double* cVaI_host);
+
+/* ---- marker effects (replicated on every rank) --------------------------- */
+int hgibbs_set_beta(hgibbs_t h, const double* beta_host);
+int hgibbs_get_beta(hgibbs_t h, double* beta_host, int32_t* components_host, double* acum_host);
+/* per-group sum of beta^2 in marker order (src/BayesRRm.cpp:2496-2499) */
+int hgibbs_beta_sqnorm(hgibbs_t h, double* bsq_host /* G */);
+
+/* ---- the sweep: src/BayesRRm.cpp:1709-2025 (+ :2468-2487) for all M markers
+ * in the given order.  order_host[M]; sigmaG_host[G]; estPi_host[G*K];
+ * adaV_host[M] (0 = marker frozen out, :1740,:1923-1926).  rng: in = state
+ * before the first marker, out = state after the last.  cass_host[G*K] is
+ * zeroed then counted (:1697,:1904).  nnz_updates = markers with
+ * deltaBeta != 0 (fixes the algorithmic byte count of the sweep). */
+int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const double* sigmaG_host,
+                 const double* estPi_host, const uint8_t* adaV_host, hgibbs_rng_state* rng, int32_t* cass_host,
+                 uint64_t* nnz_updates);
+
+/* Tuning knobs (not part of the reference's behaviour): name/value pairs such
+ * as "batch" (speculative batch width), "mode" (0 per-marker, 1 batched). */
+int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value);
+/* Statistics of the last sweep: launches, markers per launch, device time of
+ * the sweep in ms (HIP events on the sweep's stream). */
+typedef struct {
+    uint64_t launches;
+    uint64_t nnz_updates;
+    double device_ms;
+    double kernel_ms_avg; /* average duration of the dominant kernel's launches */
+} hgibbs_sweep_stats;
+int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
+
+/* ======================================================================== */
+/* Host driver: the body of BayesRRm::runMpiGibbs (src/BayesRRm.cpp:933-2939)
+ * for --mpibayes bayesMPI, restated on top of hgibbs_*.                     */
+/* ======================================================================== */
+typedef struct hydra_chain* hydra_chain_t;
+
+typedef struct {
+    uint32_t seed;          /* --seed */
+    int32_t shuffle;        /* --shuf-mark */
+    int32_t G, K;           /* groups, mixture components incl. the zero one */
+    const int32_t* groups;  /* M, or NULL for one group (src/BayesRRm.cpp:984-996) */
+    const double* mS;       /* G*K, column 0 == 0.0 */
+} hydra_model_desc;
+
+/* y_host: phenotypes of the kept individuals of ALL ranks (n_global entries,
+ * NA rows removed); the chain centres/scales it (src/BayesRRm.cpp:1564-1579). */
+int hydra_chain_create(hgibbs_t dev, const hydra_model_desc* model, const double* y_host, hydra_chain_t* out);
+int hydra_chain_destroy(hydra_chain_t c);
+/* one Gibbs iteration: mu, shuffle, sweep, sigmaG/pi per group, sigmaE */
+int hydra_chain_iterate(hydra_chain_t c);
+/* hyper-parameters after the last iteration; any pointer may be NULL */
+int hydra_chain_state(hydra_chain_t c, double* sigmaE, double* mu, double* sigmaG /*G*/, double* estPi /*G*K*/,
+                      int32_t* m0 /*G*/, int32_t* cass /*G*K*/, hgibbs_rng_state* rng);
+/* the .csv line of src/BayesRRm.cpp:2742-2760 for the given iteration number */
+int hydra_chain_csv_line(hydra_chain_t c, uint32_t iteration, char* buf, size_t len);
+const int32_t* hydra_chain_order(hydra_chain_t c);
+/* markers with deltaBeta != 0 in the last sweep */
+uint64_t hydra_chain_last_nnz(hydra_chain_t c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGIBBS_H */

@@ -1,0 +1,197 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(include/hgibbs.h), against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for integer work (counts, mixture-component indices, cass,
+RNG state) and for the residual update (same three constants, one add);
+|beta - beta_ref| <= 1e-9 * max(1, |beta_ref|) and hyper-parameters to rel
+1e-9 for floating point (the device sums in a different,
+fixed order than the oracle's sequential loop).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from hydra_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+BETA_TOL = 1e-9
+
+
+def close(a, b, tol=BETA_TOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))
+
+
+def make_case(M, N, seed=7, missing_rate=0.02):
+    geno = synth.make_genotypes(M, N, seed=seed, missing_rate=missing_rate)
+    y, _ = synth.make_phenotype(geno, seed=seed + 1, h2=0.5, causal_frac=0.05)
+    return synth.pack_bed_columns(geno), y
+
+
+@pytest.mark.parametrize("N", [37, 1024, 4099, 9001])
+def test_marker_stats_bit_exact(oracle, N):
+    M = 25
+    bed, _ = make_case(M, N, seed=N)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    mave, mstd, n1, n2, nm = dev.marker_stats()
+    for j in range(M):
+        c = [C.c_uint64() for _ in range(4)]
+        col = np.ascontiguousarray(bed[j])
+        oracle.orc_bed_counts(orc.u8ptr(col), N, *[C.byref(x) for x in c])
+        assert (n1[j], n2[j], nm[j]) == (c[1].value, c[2].value, c[3].value)
+        a, s = C.c_double(), C.c_double()
+        oracle.orc_marker_stats(c[1].value, c[2].value, c[3].value, N, C.byref(a), C.byref(s))
+        assert mave[j] == a.value and mstd[j] == s.value
+    # the packed shard comes back unchanged
+    assert np.array_equal(dev.get_bed(), bed)
+
+
+@pytest.mark.parametrize("N", [37, 4099])
+def test_residual_roundtrip_and_reductions(N):
+    bed, y = make_case(5, N, seed=3)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_residual(y)
+    assert np.array_equal(dev.get_residual(), y)
+    s, q = dev.reduce_eps()
+    assert abs(s - y.sum()) <= 1e-12 * max(1.0, np.abs(y).sum())
+    assert abs(q - (y * y).sum()) <= 1e-12 * (y * y).sum()
+    dev.add_scalar(0.375)
+    assert np.array_equal(dev.get_residual(), y + 0.375)
+    # padding slots stay zero: the sum only moved by N * c
+    s2, _ = dev.reduce_eps()
+    assert abs(s2 - (y + 0.375).sum()) <= 1e-12 * max(1.0, np.abs(y + 0.375).sum())
+
+
+@pytest.mark.parametrize("N", [37, 1023, 4099])
+def test_dot_and_update_single_marker(oracle, N):
+    M = 12
+    bed, y = make_case(M, N, seed=11 + N, missing_rate=0.05)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    mave, mstd, *_ = dev.marker_stats()
+    eps = y.copy()
+    dev.set_residual(eps)
+    rng = np.random.default_rng(5)
+    for j in range(M):
+        col = np.ascontiguousarray(bed[j])
+        ref = oracle.orc_dot(orc.u8ptr(col), orc.dptr(eps), N, mave[j], mstd[j])
+        got = dev.dot_marker(j)
+        scale = np.abs(eps).sum() * mstd[j] * 2
+        assert abs(got - ref) <= 1e-13 * scale
+        db = float(rng.normal()) * 0.01
+        oracle.orc_update(orc.u8ptr(col), orc.dptr(eps), N, mave[j], mstd[j], db)
+        dev.update_marker(j, db)
+        assert np.array_equal(dev.get_residual(), eps)  # bit-exact: same constants, one add
+
+
+def _gpu_sweep_vs_oracle(oracle, M, N, G, mS, groups, batch, iters=3, missing_rate=0.02, seed=1222):
+    bed, y = make_case(M, N, seed=M + N, missing_rate=missing_rate)
+    ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_option("batch", batch)
+    ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=seed, shuffle=1)
+    for it in range(iters):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st = ch.state()
+        assert np.array_equal(ch.order(), ref.arr("order")), "marker order diverged at it %d" % it
+        assert np.array_equal(comp, ref.arr("components")), "component indices differ at it %d" % it
+        assert np.array_equal(st["cass"].ravel(), ref.arr("cass"))
+        assert close(beta, ref.arr("beta")), "beta beyond tolerance at it %d" % it
+        assert close(acum, ref.arr("acum"))
+        assert close(st["sigmaG"], ref.arr("sigmaG")) and close(st["estPi"].ravel(), ref.arr("estPi"))
+        assert close(st["sigmaE"], ref.sigmaE) and close(st["mu"], ref.mu)
+        rx, ridx = ref.rng_state()
+        assert st["rng_idx"] % 624 == ridx % 624 and np.array_equal(st["rng_x"], rx) or \
+            _same_stream(st["rng_x"], st["rng_idx"], rx, ridx)
+        assert close(dev.get_residual(), ref.arr("eps"), 1e-9)
+        assert ch.last_nnz() == oracle.orc_chain_last_nnz(ref.h)
+    return ch, ref
+
+
+def _same_stream(xa, ia, xb, ib):
+    """Two MT19937 states are the same generator iff their next outputs agree
+    (idx 624 with the old block == idx 0 with the twisted block)."""
+    L = orc.load()
+    ga, gb = orc.OrcMt(), orc.OrcMt()
+    for g, x, i in ((ga, xa, ia), (gb, xb, ib)):
+        for k in range(624):
+            g.x[k] = int(x[k])
+        g.idx = int(i)
+    return all(L.orc_rng_u32(ga) == L.orc_rng_u32(gb) for _ in range(1300))
+
+
+@pytest.mark.parametrize("batch", [1, 7, 32, 64])
+def test_chain_vs_oracle_small(oracle, batch):
+    _gpu_sweep_vs_oracle(oracle, M=300, N=517, G=1, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), groups=None,
+                         batch=batch, iters=4)
+
+
+def test_chain_vs_oracle_groups(oracle):
+    M = 400
+    groups = (np.arange(M) % 2).astype(np.int32)
+    mS = np.array([[0.0, 0.001, 0.01, 0.1], [0.0, 0.001, 0.01, 0.1]])
+    _gpu_sweep_vs_oracle(oracle, M=M, N=4099, G=2, mS=mS, groups=groups, batch=32, iters=5)
+
+
+def test_chain_vs_oracle_long(oracle):
+    # crosses several MT19937 block boundaries on the device and on the host
+    _gpu_sweep_vs_oracle(oracle, M=1500, N=2048, G=1, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), groups=None,
+                         batch=32, iters=10, missing_rate=0.0)
+
+
+def test_batch_width_does_not_change_the_chain():
+    """Speculative batching is exact: any batch width gives bit-identical output."""
+    bed, y = make_case(500, 3000, seed=99)
+    outs = []
+    for batch in (1, 16, 64):
+        dev = capi.Device(0)
+        dev.load_bed(bed, 3000)
+        dev.set_option("batch", batch)
+        ch = capi.Chain(dev, y, seed=5)
+        for _ in range(3):
+            ch.iterate()
+        outs.append((dev.get_beta(), dev.get_residual(), ch.state()))
+    for o in outs[1:]:
+        for a, b in zip(o[0], outs[0][0]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(o[1], outs[0][1])
+        assert o[2]["sigmaE"] == outs[0][2]["sigmaE"] and np.array_equal(o[2]["rng_x"], outs[0][2]["rng_x"])
+
+
+def test_na_phenotype_rows_are_dropped(oracle):
+    M, N = 60, 1000
+    bed, y = make_case(M, N, seed=21)
+    keep = np.ones(N, dtype=np.uint8)
+    keep[[0, 5, 6, 7, 500, 999]] = 0
+    dev = capi.Device(0)
+    dev.load_bed(bed, N, keep=keep)
+    nk = int(keep.sum())
+    assert dev.n_local == nk
+    got = dev.get_bed()
+    for j in range(M):
+        out = np.zeros((nk + 3) // 4, dtype=np.uint8)
+        n_out = C.c_uint32()
+        oracle.orc_bed_compact(orc.u8ptr(np.ascontiguousarray(bed[j])), N, orc.u8ptr(keep), orc.u8ptr(out), C.byref(n_out))
+        assert n_out.value == nk and np.array_equal(got[j], out)
+
+
+def test_synth_bed_matches_host_hash():
+    from hydra_amd.synth import synth_bed_reference
+    N, M = 1003, 17
+    dev = capi.Device(0)
+    dev.synth_bed(N, M, seed=42, missing_rate=0.01)
+    assert np.array_equal(dev.get_bed(), synth_bed_reference(N, M, seed=42, missing_rate=0.01))
+    # sharding by rows reproduces the same matrix
+    dev2 = capi.Device(0)
+    dev2.synth_bed(N, M, seed=42, missing_rate=0.01, row_begin=500, row_end=1003)
+    full = synth.unpack_bed_columns(dev.get_bed(), N)
+    part = synth.unpack_bed_columns(dev2.get_bed(), 503)
+    assert np.array_equal(part, full[:, 500:])
