@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs markers/sec/iteration of the BayesRR hot path on MI355X.
+
+A "step" is one full Gibbs iteration of BayesRRm::runMpiGibbs (mu, shuffle, the
+sweep over all M markers, sigmaG/pi, sigmaE) on synthetic genotypes generated
+directly in HBM.  The headline workload is the one
+BASELINE.json's metric is quoted on: N = 500 000 individuals, M = 1 000 000
+markers (125 GB of packed .bed resident in HBM); at --gpus G the individuals
+are sharded G ways ("strong" scaling: total work fixed).
+
+    python bench.py --gpus 1 --steps 3 --warmup 2
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (N, M, groups, mS)
+    "c1": (5000, 10000, 1, [[0.0, 0.0001, 0.001, 0.01]]),
+    "c2": (50000, 100000, 1, [[0.0, 0.0001, 0.001, 0.01]]),
+    "c3": (200000, 500000, 2, [[0.0, 0.001, 0.01, 0.1], [0.0, 0.001, 0.01, 0.1]]),
+    "c4": (500000, 1000000, 1, [[0.0, 0.0001, 0.001, 0.01]]),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X nominal (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+
+
+def algorithmic_bytes(n_local, M, nnz):
+    """BASELINE.md section 3 / SURVEY.md 8(d): per marker ceil(N_g/4) + 8 N_g,
+    plus 16 N_g for every marker whose effect changed; per iteration 16 N_g + 20 M."""
+    col = (n_local + 3) // 4
+    return M * (col + 8 * n_local) + nnz * 16 * n_local + 16 * n_local + 20 * M
+
+
+def make_phenotype_on_device(dev, n_global, M, rank_rows, seed, h2=0.5, causal_frac=0.01):
+    """y = X_std beta + e built with the product's own residual-update operator:
+    eps <- e, then eps += beta_j x_j for the causal markers.  Returns y (all
+    rows on every rank: the update is replayed on the local shard and gathered
+    by the caller when sharded)."""
+    rng = np.random.default_rng(seed)
+    m_causal = max(1, int(round(M * causal_frac)))
+    causal = rng.choice(M, size=m_causal, replace=False)
+    beta = rng.normal(0.0, np.sqrt(h2 / m_causal), size=m_causal)
+    e = rng.normal(0.0, np.sqrt(1.0 - h2), size=n_global)
+    lo, hi = rank_rows
+    dev.set_residual(e[lo:hi])
+    for j, b in zip(causal, beta):
+        dev.update_marker(int(j), -float(b))  # eps += b * x_j
+    return dev.get_residual()
+
+
+def cpu_baseline(dev, y_local_is_full, y, N, M, mS, groups, sample_markers, threads):
+    """The oracle (CPU restatement of hydra's path, OpenMP over individuals as
+    the reference's loops are) timed on a bounded sample: the first
+    `sample_markers` columns of the same genotype matrix, one Gibbs iteration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    lib_name = "liboracle_omp.so"
+    if not os.path.exists(os.path.join(ROOT, "oracle", lib_name)):
+        lib_name = "liboracle.so"
+        threads = 1
+    L = orc.load(lib_name)
+    L.orc_set_threads(threads)
+    ms = min(sample_markers, M)
+    bed = dev.get_bed(0, ms)
+    g = None if groups is None else np.ascontiguousarray(groups[:ms])
+    ch = orc.Chain(L, bed, N, y, groups=g, mS=np.array(mS), seed=1222, shuffle=1)
+    ch.iterate()  # warm-up iteration (first touch, beta = 0 start)
+    t0 = time.perf_counter()
+    ch.iterate()
+    dt = time.perf_counter() - t0
+    return {"value": ms / dt, "unit": "markers/s", "cores": threads, "kind": "port",
+            "sample": "first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s" % (ms, M, N, lib_name)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--N", type=int, default=0, help="override individuals")
+    ap.add_argument("--M", type=int, default=0, help="override markers")
+    ap.add_argument("--batch", type=int, default=0, help="speculative batch width (0 = library default)")
+    ap.add_argument("--cpg", type=int, default=0, help="columns per workgroup column-group")
+    ap.add_argument("--missing", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="markers in the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane only
+
+    from hydra_amd import capi
+
+    N, M, G, mS = CONFIGS[args.config]
+    if args.N:
+        N = args.N
+    if args.M:
+        M = args.M
+    groups = None if G == 1 else (np.arange(M) % G).astype(np.int32)
+
+    # individuals sharded in multiples of 4 (byte-aligned column slices)
+    per = ((N + world - 1) // world + 3) // 4 * 4
+    lo, hi = min(N, rank * per), min(N, (rank + 1) * per)
+
+    dev = capi.Device(local_rank)
+    if world > 1:
+        uid = [capi.Device.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dev.comm_init(world, rank, uid[0])
+    if args.batch:
+        dev.set_option("batch", args.batch)
+    if args.cpg:
+        dev.set_option("cols_per_group", args.cpg)
+
+    t_setup = time.perf_counter()
+    dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)
+    y_loc = make_phenotype_on_device(dev, N, M, (lo, hi), seed=43)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, y_loc)
+        y = np.concatenate(parts)
+    else:
+        y = y_loc
+    chain = capi.Chain(dev, y, mS=np.array(mS), groups=groups, seed=1222, shuffle=1)
+    t_setup = time.perf_counter() - t_setup
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        chain.iterate()
+
+    sync()
+    stats = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.iterate()  # returns only after the sweep's stream has drained
+        stats.append((dev.sweep_stats(), chain.last_nnz()))
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = dt / K * 1e3
+        value = M * K / dt
+        n_local = hi - lo
+        sweep_ms = sum(s["device_ms"] for s, _ in stats)
+        launches = sum(s["launches"] for s, _ in stats)
+        nnz = sum(n for _, n in stats)
+        bytes_alg = sum(algorithmic_bytes(n_local, M, n) for _, n in stats)
+        kernel_ms_avg = sweep_ms / max(1, launches)
+        achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
+        out = {
+            "metric": "Gibbs markers/sec/iter",
+            "value": value,
+            "unit": "markers/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BayesRR %s: N=%d individuals x M=%d markers, K=%d mixture, G=%d groups, "
+                                   ".bed resident in HBM, individuals sharded over %d GPU(s)"
+                                   % (args.config, N, M, len(mS[0]), G, world),
+                       "N": N, "M": M, "batch": args.batch or 32, "nnz_updates_per_iter": nnz / K,
+                       "launches_per_iter": launches / K, "setup_s": t_setup},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
+                         "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
+                         "sweep_ms_per_iter": sweep_ms / K},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+            sample = args.cpu_sample or max(64, min(M, int(4.0e9 / max(1, N))))
+            out["cpu_baseline"] = cpu_baseline(dev, True, y, N, M, mS, groups, sample, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

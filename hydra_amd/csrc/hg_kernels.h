@@ -46,7 +46,9 @@ constexpr int TILE = WAVE * IPT;         // 1024 individuals per wave tile
 constexpr int BLOCK_WAVES = 4;
 constexpr int BLOCK = WAVE * BLOCK_WAVES;       // 256 threads
 constexpr int BLOCK_IND = TILE * BLOCK_WAVES;   // 4096 individuals per block
-constexpr int MAX_BATCH = 64;            // speculative batch width upper bound (one wave walks it)
+constexpr int MAX_BATCH = 256;           // speculative batch width upper bound (one thread per column in the draw)
+constexpr int MAX_CPG = 16;              // columns per workgroup column-group (register accumulators)
+constexpr int S_CAP = 64;                // max tile-group slices (gridDim.x): one partial row = 64 doubles
 constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
@@ -94,10 +96,11 @@ struct SweepParams {
     ZigTables zig;
     // hand-off
     SweepDesc* desc;
-    double* partials;      // [(3*MAX_BATCH + 1)][nblk_x], written sc1
+    double* partials;      // [(3*MAX_BATCH + 1)][S_CAP], written sc1
     uint32_t* ticket;
     uint32_t nblk_x;
     uint32_t cols_per_group; // columns handled per blockIdx.y
+    uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     // multi-GPU: when non-null the kernel stops after the local reduction and
     // leaves sums[3*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;

@@ -23,15 +23,61 @@ struct LdsGen {
     }
 };
 
+// LDS carve-up (dynamic, sized by the host from batch capacity, K and cols_per_group
+// so that the streaming workgroups keep their occupancy):
 struct SweepShared {
-    uint32_t mt[MT_BUF];
-    double wpart[BLOCK_WAVES][3 * MAX_BATCH + 1];
-    double tot[3 * MAX_BATCH + 1];
-    double thr[MAX_BATCH][MAX_K];
-    double muk[MAX_BATCH][MAX_K];
-    uint32_t flag_last;
-    uint32_t new_idx;
+    uint32_t* mt;      // MT_BUF words: current + next MT19937 block
+    double* zig_nx;    // 129 + 129: normal Ziggurat layers staged for the draw
+    double* zig_ny;
+    double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns (+ sum of eps)
+    double* tot;       // 3*bcap + 1 reduced sums
+    double* thr;       // [bcap][K-1]
+    double* muk;       // [bcap][K]
+    double* bold;      // [bcap]
+    double* mave;
+    double* mstd;
+    int32_t* marker;
+    int32_t* grp;
+    uint32_t* flags;   // [0] last-arriver flag, [1] stream position after the walk
+    uint8_t* ada;
+    uint32_t wstride;  // 3*cpg + 1
+    uint32_t bcap;     // batch capacity of this launch
 };
+
+__host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K)
+{
+    size_t n = 0;
+    n += MT_BUF * 4;
+    n += 2 * 130 * 8;
+    n += (size_t)BLOCK_WAVES * (3 * cpg + 1) * 8;
+    n += (size_t)(3 * bcap + 1) * 8;
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)bcap * K * 8 + (size_t)3 * bcap * 8;
+    n += (size_t)2 * bcap * 4 + 16 + bcap;
+    return (n + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint32_t bcap, uint32_t cpg, int K)
+{
+    SweepShared sh;
+    unsigned char* q = base;
+    sh.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
+    sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
+    sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
+    sh.wstride = 3 * cpg + 1;
+    sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
+    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(3 * bcap + 1) * 8;
+    sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
+    sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
+    sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.mave = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.mstd = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
+    sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
+    sh.flags = reinterpret_cast<uint32_t*>(q); q += 16;
+    sh.ada = q;
+    sh.bcap = bcap;
+    return sh;
+}
 
 // Next 624 untempered words from the current block, 256 threads, into mt[624..1247].
 __device__ __forceinline__ void mt_next_block(uint32_t* mt, int tid)
@@ -46,55 +92,82 @@ __device__ __forceinline__ void mt_next_block(uint32_t* mt, int tid)
     __syncthreads();
 }
 
+// Per-thread marker metadata for the draw phase; loaded EARLY (before the
+// partial reduction) so that its dependent global loads overlap the reduction.
+struct MarkerMeta {
+    int marker, grp;
+    bool ada;
+    double bold, mave, mstd;
+};
+
+__device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, const SweepDesc& d, uint32_t nb, int tid)
+{
+    MarkerMeta m{-1, 0, false, 0.0, 0.0, 0.0};
+    if ((uint32_t)tid < nb) {
+        m.marker = p.order[d.cursor + tid];
+        m.grp = p.groups[m.marker];
+        m.ada = p.adaV[m.marker] != 0;
+        m.bold = p.beta[m.marker];
+        m.mave = p.mave[m.marker];
+        m.mstd = p.mstd[m.marker];
+    }
+    return m;
+}
+
+// stage generator + normal tables in LDS (issued early as well)
+__device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShared& sh, int tid)
+{
+    for (int i = tid; i < MT_N; i += BLOCK) sh.mt[i] = p.mt[i];
+    for (int i = tid; i < 129; i += BLOCK) {
+        sh.zig_nx[i] = p.zig.nx[i];
+        sh.zig_ny[i] = p.zig.ny[i];
+    }
+}
+
 // Posterior + draw + bookkeeping for the nb markers of this batch, given the
 // reduced sums in sh.tot: rows [3j..3j+2] = (S1,S2,SM) of batch column j, row
-// 3*MAX_BATCH = sum of eps.  Runs in ONE workgroup of 256 threads.
+// 3*MAX_BATCH = sum of eps.  Runs in ONE workgroup of 256 threads; the caller
+// has already run stage_rng() and load_marker_meta() and a __syncthreads().
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; sparse dot algebra :325-341.
-__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb, SweepShared& sh)
+__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh,
+                                                 const MarkerMeta& mm)
 {
     const int tid = threadIdx.x;
     const int K = p.K;
-
-    // stage the generator
-    for (int i = tid; i < MT_N; i += BLOCK) sh.mt[i] = p.mt[i];
-    __syncthreads();
     const uint32_t idx0 = d.rng_idx;
-    const bool need_next = idx0 + 2 * MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
+    const bool need_next = idx0 + MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
     if (need_next) mt_next_block(sh.mt, tid);
 
     // ---- per-marker posterior, one thread per batch column -----------------
-    int marker = -1, grp = 0;
-    bool ada = false;
-    double bold = 0.0, mave = 0.0, mstd = 0.0, thr0 = 1.0;
     if ((uint32_t)tid < nb) {
-        marker = p.order[d.cursor + tid];
-        grp = p.groups[marker];
-        ada = p.adaV[marker] != 0;
-        bold = p.beta[marker];
-        mave = p.mave[marker];
-        mstd = p.mstd[marker];
-        if (ada) {
+        sh.marker[tid] = mm.marker;
+        sh.grp[tid] = mm.grp;
+        sh.ada[tid] = mm.ada ? 1 : 0;
+        sh.bold[tid] = mm.bold;
+        sh.mave[tid] = mm.mave;
+        sh.mstd[tid] = mm.mstd;
+        if (mm.ada) {
             const double S1 = sh.tot[3 * tid], S2 = sh.tot[3 * tid + 1], SM = sh.tot[3 * tid + 2];
-            const double Sall = sh.tot[3 * MAX_BATCH];
+            const double Sall = sh.tot[3 * sh.bcap];
             double dp = 0.0;
             dp += S1 * 1.0;
             dp += S2 * 2.0;
             double syt = Sall;
             syt -= SM;
-            dp -= (mave * syt);
-            dp *= mstd;
+            dp -= (mm.mave * syt);
+            dp *= mm.mstd;
             double num = dp;
-            num += bold * p.n_minus_1;
+            num += mm.bold * p.n_minus_1;
 
             double logL[MAX_K];
-            const double* den = p.denom + (size_t)grp * K;
-            const double* lpi = p.logpi + (size_t)grp * K;
-            const double* hlg = p.hlog + (size_t)grp * K;
+            const double* den = p.denom + (size_t)mm.grp * K;
+            const double* lpi = p.logpi + (size_t)mm.grp * K;
+            const double* hlg = p.hlog + (size_t)mm.grp * K;
             logL[0] = lpi[0];
-            sh.muk[tid][0] = 0.0;
+            sh.muk[tid * K] = 0.0;
             for (int k = 1; k < K; ++k) {
                 double mk = num / den[k];
-                sh.muk[tid][k] = mk;
+                sh.muk[tid * K + k] = mk;
                 logL[k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
             }
             // cumulative thresholds of the component walk (:1883-1921)
@@ -109,8 +182,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                 for (int k = 0; k < K; ++k) s += exp(logL[k] - logL[0]);
                 acum = 1.0 / s;
             }
-            thr0 = acum;
-            sh.thr[tid][0] = acum;
+            sh.thr[tid * (K - 1)] = acum;
             for (int k = 0; k + 2 < K; ++k) {
                 bool big2 = false;
                 for (int l = k + 1; l < K; ++l)
@@ -122,96 +194,120 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                     for (int l = 0; l < K; ++l) s += exp(logL[l] - logL[k + 1]);
                     acum += 1.0 / s;
                 }
-                sh.thr[tid][k + 1] = acum;
+                sh.thr[tid * (K - 1) + k + 1] = acum;
             }
         }
     }
     __syncthreads();
 
-    // ---- the walk: wave 0 consumes the stream in marker order ---------------
+    // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
     if (tid < WAVE) {
         const int lane = tid;
-        const bool valid = (uint32_t)lane < nb;
-        const unsigned long long am = __ballot(valid && ada);
-        const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-        int k = 0;
-        if (valid && ada) {
-            const uint32_t u = mt_temper(sh.mt[idx0 + jeff]);
-            const double prob = (double)u * (1.0 / 4294967296.0);
-            k = K - 1;
-            for (int kk = K - 2; kk >= 0; --kk)
-                if (prob <= sh.thr[lane][kk]) k = kk; // ends at the FIRST kk that accepts
-        }
-        const bool event = valid && (ada ? (k != 0 || bold != 0.0) : (bold != 0.0));
-        const unsigned long long em = __ballot(event);
-        const uint32_t f = em ? (uint32_t)(__ffsll((long long)em) - 1) : nb; // first event
-        const uint32_t naccept = (f < nb) ? f + 1 : nb;
-
-        double bnew = 0.0;
-        uint32_t consumed = 0, gerr = 0;
-        if ((uint32_t)lane == f && ada && k > 0) {
-            LdsGen g{sh.mt, idx0 + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
-            bnew = norm_rng_sd(g, p.zig, sh.muk[lane][k], p.sdk[(size_t)grp * K + k]);
-            consumed = g.pos - (idx0 + jeff + 1u);
-            gerr = g.err;
-        }
-        const double dbeta = bold - bnew;
-
-        // results of accepted markers (:1892,:1899-1905,:1924-1925)
-        if ((uint32_t)lane < naccept) {
+        uint32_t pos = idx0;       // stream position (words consumed so far = pos - idx0)
+        uint32_t naccept = 0;      // markers accepted so far
+        int f_marker = -1;
+        double f_dbeta = 0.0, f_mave = 0.0, f_mstd = 0.0;
+        uint32_t f_err = 0;
+        bool stopped = false;
+        for (uint32_t base = 0; base < nb && !stopped; base += WAVE) {
+            const uint32_t j = base + lane;
+            const bool valid = j < nb;
+            const bool ada = valid && sh.ada[valid ? j : 0] != 0;
+            const double bold = valid ? sh.bold[j] : 0.0;
+            const int grp = valid ? sh.grp[j] : 0;
+            const int marker = valid ? sh.marker[j] : -1;
+            const unsigned long long am = __ballot(ada);
+            const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+            int k = 0;
             if (ada) {
-                const int kk = ((uint32_t)lane == f) ? k : 0;
-                p.beta[marker] = ((uint32_t)lane == f) ? bnew : 0.0;
-                p.comp[marker] = kk;
-                p.acum[marker] = thr0;
-                atomicAdd(&p.cass[grp * K + kk], 1);
-            } else {
-                p.beta[marker] = 0.0;
-                p.acum[marker] = 1.0;
+                const uint32_t u = mt_temper(sh.mt[pos + jeff]);
+                const double prob = (double)u * (1.0 / 4294967296.0);
+                k = K - 1;
+                for (int kk = K - 2; kk >= 0; --kk)
+                    if (prob <= sh.thr[j * (K - 1) + kk]) k = kk; // ends at the FIRST kk that accepts
+            }
+            const bool event = valid && (ada ? (k != 0 || bold != 0.0) : (bold != 0.0));
+            const unsigned long long em = __ballot(event);
+            const uint32_t nvalid = (nb - base < (uint32_t)WAVE) ? nb - base : (uint32_t)WAVE;
+            const uint32_t f = em ? (uint32_t)(__ffsll((long long)em) - 1) : nvalid; // first event in this chunk
+            const uint32_t nacc = (f < nvalid) ? f + 1 : nvalid;
+
+            double bnew = 0.0;
+            uint32_t consumed = 0, gerr = 0;
+            if ((uint32_t)lane == f && ada && k > 0) {
+                LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
+                ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
+                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], p.sdk[(size_t)grp * K + k]);
+                consumed = g.pos - (pos + jeff + 1u);
+                gerr = g.err;
+            }
+            const double dbeta = bold - bnew;
+
+            // results of accepted markers (:1892,:1899-1905,:1924-1925)
+            if ((uint32_t)lane < nacc) {
+                if (ada) {
+                    const int kk = ((uint32_t)lane == f) ? k : 0;
+                    p.beta[marker] = ((uint32_t)lane == f) ? bnew : 0.0;
+                    p.comp[marker] = kk;
+                    p.acum[marker] = sh.thr[j * (K - 1)];
+                    atomicAdd(&p.cass[grp * K + kk], 1);
+                } else {
+                    p.beta[marker] = 0.0;
+                    p.acum[marker] = 1.0;
+                }
+            }
+            const uint32_t used = (uint32_t)__popcll(am & ((nacc >= 64u) ? ~0ull : ((1ull << nacc) - 1ull)));
+            naccept += nacc;
+            pos += used;
+            if (f < nvalid) { // an event ends the batch (later dots are stale)
+                stopped = true;
+                const int src = (int)f;
+                f_dbeta = __shfl(dbeta, src, 64);
+                f_marker = __shfl(marker, src, 64);
+                f_mave = sh.mave[base + f];
+                f_mstd = sh.mstd[base + f];
+                pos += (uint32_t)__shfl((int)consumed, src, 64);
+                f_err = (uint32_t)__shfl((int)gerr, src, 64);
             }
         }
-
         // hand the state to the next launch
-        const uint32_t used = (uint32_t)__popcll(am & ((naccept >= 64u) ? ~0ull : ((1ull << naccept) - 1ull)));
-        const int src = (f < nb) ? (int)f : 0;
-        const double f_dbeta = __shfl(dbeta, src, 64);
-        const double f_mave = __shfl(mave, src, 64);
-        const double f_mstd = __shfl(mstd, src, 64);
-        const int f_marker = __shfl(marker, src, 64);
-        const uint32_t f_consumed = (uint32_t)__shfl((int)consumed, src, 64);
-        const uint32_t f_err = (uint32_t)__shfl((int)gerr, src, 64);
         if (lane == 0) {
             SweepDesc n = d;
             n.cursor = d.cursor + naccept;
             if (d.pend_marker >= 0) n.cur = d.cur ^ 1u;
             n.pend_marker = -1;
-            if (f < nb && f_dbeta != 0.0) {
+            if (stopped && f_dbeta != 0.0) {
                 n.pend_marker = f_marker;
                 n.pv[0] = -(f_mave * f_mstd * f_dbeta);
                 n.pv[1] = f_dbeta * (1.0 - f_mave) * f_mstd;
                 n.pv[2] = f_dbeta * (2.0 - f_mave) * f_mstd;
                 n.nnz = d.nnz + 1;
             }
-            uint32_t nidx = idx0 + used + ((f < nb) ? f_consumed : 0u);
-            sh.new_idx = nidx;
-            if (nidx >= (uint32_t)MT_N) nidx -= (uint32_t)MT_N;
-            n.rng_idx = nidx;
+            sh.flags[1] = pos;
+            n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
             n.launches = d.launches + 1;
             n.accepted_sum = d.accepted_sum + naccept;
-            if (f < nb && f_err) n.error = f_err;
+            if (f_err) n.error = f_err;
             *p.desc = n;
         }
     }
     __syncthreads();
     // generator crossed into the next block: make it the current one
-    if (sh.new_idx >= (uint32_t)MT_N)
+    if (sh.flags[1] >= (uint32_t)MT_N)
         for (int i = tid; i < MT_N; i += BLOCK) p.mt[i] = sh.mt[MT_N + i];
 }
 
-// One launch of the sweep (grid = (n_pad/4096, ceil(MAX_BATCH/cols_per_group))).
+extern __shared__ __attribute__((aligned(16))) unsigned char hg_smem[];
+
+// One launch of the sweep.  grid = (S, ceil(batch/cols_per_group)): blockIdx.y
+// owns a group of up to CPG batch columns, blockIdx.x a strided set of tile
+// groups (4 wave tiles = 4096 individuals each).  Every lane keeps the masked
+// sums of its columns in registers across all its tiles; one wave/block
+// reduction per launch, then S_CAP-strided partial rows for the last arriver.
+template <int CPG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
 {
-    __shared__ SweepShared sh;
+    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
     const SweepDesc d = *p.desc;
     const bool pend = d.pend_marker >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
@@ -219,118 +315,155 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     if ((nb == 0 && !pend) || d.error) return; // whole grid agrees: nothing left to do
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
-    const uint32_t cpg = p.cols_per_group;
-    const uint32_t c0 = blockIdx.y * cpg;
-    const uint32_t c1 = (c0 + cpg < nb) ? c0 + cpg : nb;
+    const uint32_t c0 = blockIdx.y * CPG;
+    const uint32_t c1 = (c0 + CPG < nb) ? c0 + CPG : nb;
+    const uint32_t ncol = (c1 > c0) ? c1 - c0 : 0u;
     const bool first_group = blockIdx.y == 0;
     const double* eps_in = d.cur ? p.eps1 : p.eps0;
     double* eps_out = d.cur ? p.eps0 : p.eps1;
+    const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
 
-    if (c0 < nb || first_group) {
-        double e[IPT];
-        load_eps16(eps_in, tile, lane, e);
-        if (pend) {
-            const uint32_t w =
-                *reinterpret_cast<const uint32_t*>(p.bed + (size_t)d.pend_marker * p.stride + ((size_t)tile << 8) + (lane << 2));
-            apply_update16(w, d.pv[0], d.pv[1], d.pv[2], e);
-            if (first_group) store_eps16(eps_out, tile, lane, e);
+    double a1[CPG], a2[CPG], am[CPG], sall = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) a1[c] = a2[c] = am[c] = 0.0;
+    const uint8_t* colp[CPG];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
+        const int marker = nb ? p.order[d.cursor + j] : 0;
+        colp[c] = p.bed + (size_t)marker * p.stride + (lane << 2);
+    }
+    const uint8_t* pendp = p.bed + (size_t)(pend ? d.pend_marker : 0) * p.stride + (lane << 2);
+
+    if (ncol || first_group) {
+        for (uint32_t tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
+            const uint32_t tile = tg * BLOCK_WAVES + wave;
+            double e[IPT];
+            load_eps16(eps_in, tile, lane, e);
+            uint32_t w[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8));
+            if (pend) {
+                const uint32_t wp = *reinterpret_cast<const uint32_t*>(pendp + ((size_t)tile << 8));
+                apply_update16(wp, d.pv[0], d.pv[1], d.pv[2], e);
+                if (first_group) store_eps16(eps_out, tile, lane, e);
+            }
+            if (first_group) {
+#pragma unroll
+                for (int i = 0; i < IPT; ++i) sall += e[i];
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                uint32_t m1, m2, mm;
+                code_masks(w[c], m1, m2, mm);
+#pragma unroll
+                for (int s = 0; s < IPT; ++s) {
+                    a1[c] += mask_f64(e[s], ((int)(m1 << (31 - 2 * s))) >> 31);
+                    a2[c] += mask_f64(e[s], ((int)(m2 << (31 - 2 * s))) >> 31);
+                    am[c] += mask_f64(e[s], ((int)(mm << (31 - 2 * s))) >> 31);
+                }
+            }
+        }
+        // one cross-lane reduction per launch
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]), tm = wave_sum(am[c]);
+            if (lane == 0) {
+                sh.wpart[wave * sh.wstride + 3 * c] = t1;
+                sh.wpart[wave * sh.wstride + 3 * c + 1] = t2;
+                sh.wpart[wave * sh.wstride + 3 * c + 2] = tm;
+            }
         }
         if (first_group) {
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < IPT; ++i) s += e[i];
-            s = wave_sum(s);
-            if (lane == 0) sh.wpart[wave][3 * MAX_BATCH] = s;
-        }
-        for (uint32_t j = c0; j < c1; ++j) {
-            const int marker = p.order[d.cursor + j];
-            const uint32_t w =
-                *reinterpret_cast<const uint32_t*>(p.bed + (size_t)marker * p.stride + ((size_t)tile << 8) + (lane << 2));
-            uint32_t m1, m2, mm;
-            code_masks(w, m1, m2, mm);
-            double s1 = 0.0, s2 = 0.0, sm = 0.0;
-#pragma unroll
-            for (int s = 0; s < IPT; ++s) {
-                s1 += mask_f64(e[s], ((int)(m1 << (31 - 2 * s))) >> 31);
-                s2 += mask_f64(e[s], ((int)(m2 << (31 - 2 * s))) >> 31);
-                sm += mask_f64(e[s], ((int)(mm << (31 - 2 * s))) >> 31);
-            }
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
-            sm = wave_sum(sm);
-            if (lane == 0) {
-                sh.wpart[wave][3 * j] = s1;
-                sh.wpart[wave][3 * j + 1] = s2;
-                sh.wpart[wave][3 * j + 2] = sm;
-            }
+            const double t = wave_sum(sall);
+            if (lane == 0) sh.wpart[wave * sh.wstride + 3 * CPG] = t;
         }
     }
     __syncthreads();
 
     // block partial = waves 0..3 in order, published write-through (sc1)
     {
-        const uint32_t nrow = (c1 > c0) ? 3 * (c1 - c0) : 0u;
-        if ((uint32_t)tid < nrow) {
-            const uint32_t r = 3 * c0 + tid;
-            double v = sh.wpart[0][r];
-            v += sh.wpart[1][r];
-            v += sh.wpart[2][r];
-            v += sh.wpart[3][r];
-            __hip_atomic_store(p.partials + (size_t)r * p.nblk_x + blockIdx.x, v, HG_RLX_AGENT);
+        const uint32_t nrow = 3 * ncol;
+        for (uint32_t t = tid; t < nrow; t += BLOCK) {
+            double v = sh.wpart[t];
+            v += sh.wpart[sh.wstride + t];
+            v += sh.wpart[2 * sh.wstride + t];
+            v += sh.wpart[3 * sh.wstride + t];
+            __hip_atomic_store(p.partials + (size_t)(3 * c0 + t) * S_CAP + blockIdx.x, v, HG_RLX_AGENT);
         }
         if (first_group && tid == BLOCK - 1) {
-            const uint32_t r = 3 * MAX_BATCH;
-            double v = sh.wpart[0][r];
-            v += sh.wpart[1][r];
-            v += sh.wpart[2][r];
-            v += sh.wpart[3][r];
-            __hip_atomic_store(p.partials + (size_t)r * p.nblk_x + blockIdx.x, v, HG_RLX_AGENT);
+            const uint32_t t = 3 * CPG;
+            double v = sh.wpart[t];
+            v += sh.wpart[sh.wstride + t];
+            v += sh.wpart[2 * sh.wstride + t];
+            v += sh.wpart[3 * sh.wstride + t];
+            __hip_atomic_store(p.partials + (size_t)(3 * MAX_BATCH) * S_CAP + blockIdx.x, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
     __syncthreads();
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        sh.flag_last = (t == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+        sh.flags[0] = (t == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!sh.flag_last) return;
+    if (!sh.flags[0]) return;
 
-    // ---- last-arriving workgroup: fixed-order reduction over blocks ---------
+    // ---- last-arriving workgroup ---------------------------------------------
+    // issue the latency-bound loads first: marker metadata, generator, tables
+    const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
+    if (!p.sums_out) stage_rng(p, sh, tid);
+
+    // fixed-order reduction: one thread per row, blocks 0..S-1 in order, all of
+    // a row's loads in flight together
     {
         const uint32_t nrows = 3 * nb + 1;
-        for (uint32_t rr = wave; rr < nrows; rr += BLOCK_WAVES) {
+        const uint32_t S = gridDim.x;
+        for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
             const uint32_t r = (rr == 3 * nb) ? 3 * MAX_BATCH : rr;
-            const double* row = p.partials + (size_t)r * p.nblk_x;
-            double v = 0.0;
-            for (uint32_t b = lane; b < p.nblk_x; b += WAVE) v += __hip_atomic_load(row + b, HG_RLX_AGENT);
-            v = wave_sum(v);
-            if (lane == 0) sh.tot[r] = v;
+            const double* row = p.partials + (size_t)r * S_CAP;
+            double acc = 0.0;
+            for (uint32_t b0 = 0; b0 < S; b0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = (b0 + u < S) ? __hip_atomic_load(row + b0 + u, HG_RLX_AGENT) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (b0 + u < S) acc += v[u];
+            }
+            sh.tot[(rr == 3 * nb) ? 3 * sh.bcap : rr] = acc;
         }
     }
     if (tid == 0) __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
     __syncthreads();
 
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
-        for (int r = tid; r < 3 * MAX_BATCH + 1; r += BLOCK) p.sums_out[r] = (r < 3 * (int)nb || r == 3 * MAX_BATCH) ? sh.tot[r] : 0.0;
+        for (int r = tid; r < 3 * MAX_BATCH + 1; r += BLOCK) {
+            double v = 0.0;
+            if (r < 3 * (int)nb) v = sh.tot[r];
+            if (r == 3 * MAX_BATCH) v = sh.tot[3 * sh.bcap];
+            p.sums_out[r] = v;
+        }
         return;
     }
-    sweep_draw_phase(p, d, nb, sh);
+    sweep_draw_phase(p, d, nb, sh, meta);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
 __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
-    __shared__ SweepShared sh;
+    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
     const SweepDesc d = *p.desc;
     const bool pend = d.pend_marker >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
     const uint32_t nb = d.batch < remaining ? d.batch : remaining;
     if ((nb == 0 && !pend) || d.error) return;
-    for (int r = threadIdx.x; r < 3 * MAX_BATCH + 1; r += BLOCK) sh.tot[r] = p.sums_out[r];
+    const MarkerMeta meta = load_marker_meta(p, d, nb, threadIdx.x);
+    stage_rng(p, sh, threadIdx.x);
+    for (int r = threadIdx.x; r < 3 * (int)nb; r += BLOCK) sh.tot[r] = p.sums_out[r];
+    if (threadIdx.x == 0) sh.tot[3 * sh.bcap] = p.sums_out[3 * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase(p, d, nb, sh);
+    sweep_draw_phase(p, d, nb, sh, meta);
 }
 
 } // namespace hg

@@ -100,6 +100,7 @@ struct hgibbs_ctx {
     uint32_t batch = 32;
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
+    uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
 
     hgibbs_sweep_stats stats{};
 };
@@ -489,7 +490,7 @@ static int alloc_problem(hgibbs_ctx* h, uint32_t n_global, uint32_t n_local, uin
     HIP_TRY(hipMemsetAsync(h->acum, 0, (size_t)M * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->groups, 0, (size_t)M * sizeof(int32_t), h->stream));
     const uint32_t nblk_x = h->n_pad / BLOCK_IND;
-    HIP_TRY(hipMalloc(&h->partials, (size_t)(3 * MAX_BATCH + 1) * nblk_x * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->partials, (size_t)(3 * MAX_BATCH + 1) * S_CAP * sizeof(double)));
     if (ensure_scratch(h, (size_t)nblk_x * 4 + 4096)) return 1;
     h->eps_cur = 0;
     h->have_stats = false;
@@ -778,8 +779,11 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         if (value < 1 || value > MAX_BATCH) return fail("batch must be in [1,%d]", MAX_BATCH);
         h->batch = (uint32_t)value;
     } else if (!std::strcmp(name, "cols_per_group")) {
-        if (value < 1 || value > MAX_BATCH) return fail("cols_per_group must be in [1,%d]", MAX_BATCH);
+        if (value != 2 && value != 4 && value != 8 && value != 16) return fail("cols_per_group must be 2, 4, 8 or 16");
         h->cols_per_group = (uint32_t)value;
+    } else if (!std::strcmp(name, "slices")) {
+        if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
+        h->slices = (uint32_t)value;
     } else if (!std::strcmp(name, "chunk")) {
         h->chunk = (int)value;
     } else {
@@ -835,7 +839,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->ticket, 0, 64, h->stream));
 
-    const uint32_t cpg = std::min(h->cols_per_group, h->batch);
+    const uint32_t cpg = h->cols_per_group;
     const uint32_t ngroups = (h->batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
@@ -877,9 +881,13 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.ticket = h->ticket;
     p.nblk_x = h->n_pad / BLOCK_IND;
     p.cols_per_group = cpg;
+    p.batch_cap = ngroups * cpg;
+    const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
     p.sums_out = (h->nranks > 1) ? h->sums : nullptr;
 
-    const dim3 grid(p.nblk_x, ngroups);
+    const uint32_t ntg = h->n_pad / BLOCK_IND;
+    const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
+    const dim3 grid(S, ngroups);
     uint64_t total_launches = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     double avg_accept = std::max(1.0, (double)h->batch * 0.5);
@@ -888,10 +896,15 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         const uint32_t remaining = M - std::min(M, dh.cursor);
         int n = h->chunk > 0 ? h->chunk : (int)std::min<double>(2048.0, std::max(8.0, 1.25 * remaining / avg_accept + 2));
         for (int i = 0; i < n; ++i) {
-            k_sweep_batch<<<grid, BLOCK, 0, h->stream>>>(p);
+            switch (cpg) {
+            case 2: k_sweep_batch<2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 4: k_sweep_batch<4><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 8: k_sweep_batch<8><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            default: k_sweep_batch<16><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            }
             if (h->nranks > 1) {
                 NCCL_TRY(ncclAllReduce(h->sums, h->sums, 3 * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
-                k_sweep_draw<<<1, BLOCK, 0, h->stream>>>(p);
+                k_sweep_draw<<<1, BLOCK, lds, h->stream>>>(p);
             }
         }
         total_launches += (uint64_t)n;

@@ -128,7 +128,7 @@ def _same_stream(xa, ia, xb, ib):
     return all(L.orc_rng_u32(ga) == L.orc_rng_u32(gb) for _ in range(1300))
 
 
-@pytest.mark.parametrize("batch", [1, 7, 32, 64])
+@pytest.mark.parametrize("batch", [1, 7, 32, 64, 200, 256])
 def test_chain_vs_oracle_small(oracle, batch):
     _gpu_sweep_vs_oracle(oracle, M=300, N=517, G=1, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), groups=None,
                          batch=batch, iters=4)
@@ -151,7 +151,7 @@ def test_batch_width_does_not_change_the_chain():
     """Speculative batching is exact: any batch width gives bit-identical output."""
     bed, y = make_case(500, 3000, seed=99)
     outs = []
-    for batch in (1, 16, 64):
+    for batch in (1, 16, 64, 256):
         dev = capi.Device(0)
         dev.load_bed(bed, 3000)
         dev.set_option("batch", batch)
