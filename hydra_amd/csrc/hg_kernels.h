@@ -50,6 +50,9 @@ constexpr int MAX_BATCH = 256;           // speculative batch width upper bound 
 constexpr int MAX_CPG = 16;              // columns per workgroup column-group (register accumulators)
 constexpr int S_CAP = 64;                // max tile-group slices (gridDim.x): one partial row = 64 doubles
 constexpr int MAX_K = 8;                 // mixture components incl. zero
+constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
+constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
+constexpr int ROWS_CAP = NSUM * MAX_BATCH + 8; // partial rows per slice (padded)
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
 struct SweepDesc {
@@ -79,6 +82,11 @@ struct SweepParams {
     const int32_t* groups;
     const int32_t* order;
     const uint8_t* adaV;
+    // per-marker metadata gathered into SWEEP order once per sweep (k_gather_meta)
+    const double* s_mave;
+    const double* s_mstd;
+    const double* s_bold;
+    const int32_t* s_ga;   // group | adaV << 30 | has-missing-calls << 29
     // effects
     double* beta;
     int32_t* comp;
@@ -86,6 +94,7 @@ struct SweepParams {
     int32_t* cass;         // G*K counters
     // hyper tables, G*K each (column 0 of denom/h/sd unused)
     int K;
+    int GK;                // G*K
     const double* denom;   // (N-1) + sigmaE/sigmaG[g]*cVaI[g,k]
     const double* logpi;   // log(estPi[g,k])
     const double* hlog;    // 0.5*log(sigmaG[g]/sigmaE*(N-1)*cVa[g,k] + 1)
@@ -96,24 +105,49 @@ struct SweepParams {
     ZigTables zig;
     // hand-off
     SweepDesc* desc;
-    double* partials;      // [(3*MAX_BATCH + 1)][S_CAP], written sc1
+    double* partials;      // [S_CAP][ROWS_CAP], written sc1
     uint32_t* ticket;
     uint32_t nblk_x;
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     // multi-GPU: when non-null the kernel stops after the local reduction and
-    // leaves sums[3*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
+    // leaves sums[NSUM*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;
+    unsigned long long* dbg; // optional stage timestamps (wall_clock64, 100 MHz)
 };
 
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// 64-lane sum on the VALU's DPP path (no LDS round trips): quad swaps, row
+// mirrors, then row broadcasts; fixed tree, total valid in lane 63 and returned
+// wave-uniform.  (DPP only moves 32 bits, so each step moves both halves.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_lane63(double v)
+{
+    v += dpp_f64<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v); // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v); // row_mirror: every lane of a 16-row holds the row total
+    v += dpp_f64<0x142, 0xA>(v); // row_bcast15 into rows 1,3
+    v += dpp_f64<0x143, 0xC>(v); // row_bcast31 into rows 2,3
+    return v;                    // lane 63 = total
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = wave_sum_lane63(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double mask_f64(double e, int m /* 0 or -1 */)
@@ -157,6 +191,17 @@ __device__ __forceinline__ void code_masks(uint32_t w, uint32_t& m1, uint32_t& m
     m1 = hi & ~lo & 0x55555555u;   // code 10 -> genotype 1
     m2 = ~hi & ~lo & 0x55555555u;  // code 00 -> genotype 2
     mm = ~hi & lo & 0x55555555u;   // code 01 -> missing
+}
+
+// weights of one column dword (16 codes), 2-bit fields: gw = g*nm in {0,1,2}
+// (what dotp_lut_a*dotp_lut_b tabulate), nm = non-missing in {0,1} (dotp_lut_b)
+__device__ __forceinline__ void code_weights(uint32_t w, uint32_t& gw, uint32_t& nm)
+{
+    const uint32_t hi = w >> 1, lo = w;
+    const uint32_t m1 = hi & ~lo & 0x55555555u;  // code 10 -> genotype 1
+    const uint32_t m2 = ~hi & ~lo & 0x55555555u; // code 00 -> genotype 2
+    gw = m1 | (m2 << 1);
+    nm = ~(~hi & lo) & 0x55555555u;              // everything but code 01
 }
 
 // a8 on registers: eps_s += {v0,v1,v2,0}[g_s]

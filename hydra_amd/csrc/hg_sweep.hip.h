@@ -40,6 +40,8 @@ struct SweepShared {
     int32_t* grp;
     uint32_t* flags;   // [0] last-arriver flag, [1] stream position after the walk
     uint8_t* ada;
+    double* red;       // 128 doubles: exchange buffer of the tail reduction
+    double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
     uint32_t wstride;  // 3*cpg + 1
     uint32_t bcap;     // batch capacity of this launch
 };
@@ -49,10 +51,11 @@ __host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, i
     size_t n = 0;
     n += MT_BUF * 4;
     n += 2 * 130 * 8;
-    n += (size_t)BLOCK_WAVES * (3 * cpg + 1) * 8;
-    n += (size_t)(3 * bcap + 1) * 8;
+    n += (size_t)BLOCK_WAVES * (NSUM * cpg + 1) * 8;
+    n += (size_t)(NSUM * bcap + 1) * 8;
     n += (size_t)bcap * (K - 1) * 8 + (size_t)bcap * K * 8 + (size_t)3 * bcap * 8;
-    n += (size_t)2 * bcap * 4 + 16 + bcap;
+    n += (size_t)2 * bcap * 4 + 16 + ((bcap + 15) & ~15u);
+    n += (size_t)4 * HT_LDS * 8 + 128 * 8;
     return (n + 15) & ~(size_t)15;
 }
 
@@ -63,9 +66,9 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
-    sh.wstride = 3 * cpg + 1;
+    sh.wstride = NSUM * cpg + 1;
     sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
-    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(3 * bcap + 1) * 8;
+    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NSUM * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
@@ -74,7 +77,9 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.flags = reinterpret_cast<uint32_t*>(q); q += 16;
-    sh.ada = q;
+    sh.ada = q; q += (bcap + 15) & ~15u;
+    sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
+    sh.red = reinterpret_cast<double*>(q);
     sh.bcap = bcap;
     return sh;
 }
@@ -96,20 +101,23 @@ __device__ __forceinline__ void mt_next_block(uint32_t* mt, int tid)
 // partial reduction) so that its dependent global loads overlap the reduction.
 struct MarkerMeta {
     int marker, grp;
-    bool ada;
+    bool ada, miss;
     double bold, mave, mstd;
 };
 
 __device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, const SweepDesc& d, uint32_t nb, int tid)
 {
-    MarkerMeta m{-1, 0, false, 0.0, 0.0, 0.0};
+    MarkerMeta m{-1, 0, false, false, 0.0, 0.0, 0.0};
     if ((uint32_t)tid < nb) {
-        m.marker = p.order[d.cursor + tid];
-        m.grp = p.groups[m.marker];
-        m.ada = p.adaV[m.marker] != 0;
-        m.bold = p.beta[m.marker];
-        m.mave = p.mave[m.marker];
-        m.mstd = p.mstd[m.marker];
+        const uint32_t j = d.cursor + tid; // sweep-ordered side arrays: no dependent gather
+        m.marker = p.order[j];
+        const int ga = p.s_ga[j];
+        m.grp = ga & 0x0fffffff;
+        m.ada = (ga & 0x40000000) != 0;
+        m.miss = (ga & 0x20000000) != 0;
+        m.bold = p.s_bold[j];
+        m.mave = p.s_mave[j];
+        m.mstd = p.s_mstd[j];
     }
     return m;
 }
@@ -122,11 +130,13 @@ __device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShare
         sh.zig_nx[i] = p.zig.nx[i];
         sh.zig_ny[i] = p.zig.ny[i];
     }
+    if (p.GK <= HT_LDS)
+        for (int i = tid; i < 4 * p.GK; i += BLOCK) sh.htab[(i / p.GK) * HT_LDS + (i % p.GK)] = p.denom[i]; // 4 tables are contiguous
 }
 
 // Posterior + draw + bookkeeping for the nb markers of this batch, given the
-// reduced sums in sh.tot: rows [3j..3j+2] = (S1,S2,SM) of batch column j, row
-// 3*MAX_BATCH = sum of eps.  Runs in ONE workgroup of 256 threads; the caller
+// reduced sums in sh.tot: rows [2j,2j+1] = (s1,s2) of batch column j, last row
+// = sum of eps.  Runs in ONE workgroup of 256 threads; the caller
 // has already run stage_rng() and load_marker_meta() and a __syncthreads().
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; sparse dot algebra :325-341.
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh,
@@ -147,22 +157,21 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
         sh.mave[tid] = mm.mave;
         sh.mstd[tid] = mm.mstd;
         if (mm.ada) {
-            const double S1 = sh.tot[3 * tid], S2 = sh.tot[3 * tid + 1], SM = sh.tot[3 * tid + 2];
-            const double Sall = sh.tot[3 * sh.bcap];
-            double dp = 0.0;
-            dp += S1 * 1.0;
-            dp += S2 * 2.0;
-            double syt = Sall;
-            syt -= SM;
-            dp -= (mm.mave * syt);
-            dp *= mm.mstd;
+            // dense BED form of the reference (src/BayesRRm.cpp:1785-1790,1809):
+            // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
+            // A column without missing calls has s2 == sum of eps, bit for bit
+            // (same lanes, same order), so it is not accumulated per column.
+            const double s1 = sh.tot[NSUM * tid];
+            const double s2 = mm.miss ? sh.tot[NSUM * tid + 1] : sh.tot[NSUM * sh.bcap];
+            const double dp = mm.mstd * (s1 - mm.mave * s2);
             double num = dp;
             num += mm.bold * p.n_minus_1;
 
             double logL[MAX_K];
-            const double* den = p.denom + (size_t)mm.grp * K;
-            const double* lpi = p.logpi + (size_t)mm.grp * K;
-            const double* hlg = p.hlog + (size_t)mm.grp * K;
+            const bool staged = p.GK <= HT_LDS;
+            const double* den = (staged ? sh.htab : p.denom) + (size_t)mm.grp * K;
+            const double* lpi = (staged ? sh.htab + HT_LDS : p.logpi) + (size_t)mm.grp * K;
+            const double* hlg = (staged ? sh.htab + 2 * HT_LDS : p.hlog) + (size_t)mm.grp * K;
             logL[0] = lpi[0];
             sh.muk[tid * K] = 0.0;
             for (int k = 1; k < K; ++k) {
@@ -199,6 +208,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
         }
     }
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[3] = wall_clock64();
 
     // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
     if (tid < WAVE) {
@@ -237,7 +247,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             if ((uint32_t)lane == f && ada && k > 0) {
                 LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
                 ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
-                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], p.sdk[(size_t)grp * K + k]);
+                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], (p.GK <= HT_LDS ? sh.htab + 3 * HT_LDS : p.sdk)[(size_t)grp * K + k]);
                 consumed = g.pos - (pos + jeff + 1u);
                 gerr = g.err;
             }
@@ -289,6 +299,12 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             n.accepted_sum = d.accepted_sum + naccept;
             if (f_err) n.error = f_err;
             *p.desc = n;
+            if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
+                p.dbg[4] = wall_clock64();
+                for (int i = 0; i < 4; ++i) p.dbg[8 + i] += p.dbg[i + 1] - p.dbg[i];
+                p.dbg[12] += naccept;
+                p.dbg[15] += 1;
+            }
         }
     }
     __syncthreads();
@@ -323,14 +339,22 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
 
-    double a1[CPG], a2[CPG], am[CPG], sall = 0.0;
+    // latency-bound loads of the draw phase, issued by EVERY workgroup before the
+    // streaming loop (any of them may turn out to be the last arriver)
+    const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
+    if (!p.sums_out) stage_rng(p, sh, tid);
+    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[0] = wall_clock64();
+
+    double a1[CPG], a2[CPG], sall = 0.0;
 #pragma unroll
-    for (int c = 0; c < CPG; ++c) a1[c] = a2[c] = am[c] = 0.0;
+    for (int c = 0; c < CPG; ++c) a1[c] = a2[c] = 0.0;
     const uint8_t* colp[CPG];
+    bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
         const int marker = nb ? p.order[d.cursor + j] : 0;
+        cmiss[c] = nb ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
         colp[c] = p.bed + (size_t)marker * p.stride + (lane << 2);
     }
     const uint8_t* pendp = p.bed + (size_t)(pend ? d.pend_marker : 0) * p.stride + (lane << 2);
@@ -354,50 +378,50 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             }
 #pragma unroll
             for (int c = 0; c < CPG; ++c) {
-                uint32_t m1, m2, mm;
-                code_masks(w[c], m1, m2, mm);
+                uint32_t gw, nm;
+                code_weights(w[c], gw, nm);
 #pragma unroll
-                for (int s = 0; s < IPT; ++s) {
-                    a1[c] += mask_f64(e[s], ((int)(m1 << (31 - 2 * s))) >> 31);
-                    a2[c] += mask_f64(e[s], ((int)(m2 << (31 - 2 * s))) >> 31);
-                    am[c] += mask_f64(e[s], ((int)(mm << (31 - 2 * s))) >> 31);
+                for (int s = 0; s < IPT; ++s) // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add
+                    a1[c] = __builtin_fma((double)((gw >> (2 * s)) & 3u), e[s], a1[c]);
+                if (cmiss[c]) {
+#pragma unroll
+                    for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm >> (2 * s)) & 1u), e[s], a2[c]);
                 }
             }
         }
         // one cross-lane reduction per launch
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
-            const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]), tm = wave_sum(am[c]);
+            const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
             if (lane == 0) {
-                sh.wpart[wave * sh.wstride + 3 * c] = t1;
-                sh.wpart[wave * sh.wstride + 3 * c + 1] = t2;
-                sh.wpart[wave * sh.wstride + 3 * c + 2] = tm;
+                sh.wpart[wave * sh.wstride + NSUM * c] = t1;
+                sh.wpart[wave * sh.wstride + NSUM * c + 1] = t2;
             }
         }
         if (first_group) {
             const double t = wave_sum(sall);
-            if (lane == 0) sh.wpart[wave * sh.wstride + 3 * CPG] = t;
+            if (lane == 0) sh.wpart[wave * sh.wstride + NSUM * CPG] = t;
         }
     }
     __syncthreads();
 
     // block partial = waves 0..3 in order, published write-through (sc1)
     {
-        const uint32_t nrow = 3 * ncol;
+        const uint32_t nrow = NSUM * ncol;
         for (uint32_t t = tid; t < nrow; t += BLOCK) {
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)(3 * c0 + t) * S_CAP + blockIdx.x, v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + (NSUM * c0 + t), v, HG_RLX_AGENT);
         }
         if (first_group && tid == BLOCK - 1) {
-            const uint32_t t = 3 * CPG;
+            const uint32_t t = NSUM * CPG;
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)(3 * MAX_BATCH) * S_CAP + blockIdx.x, v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + NSUM * MAX_BATCH, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
@@ -410,38 +434,42 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     if (!sh.flags[0]) return;
 
     // ---- last-arriving workgroup ---------------------------------------------
-    // issue the latency-bound loads first: marker metadata, generator, tables
-    const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
-    if (!p.sums_out) stage_rng(p, sh, tid);
+    if (p.dbg && tid == 0) p.dbg[1] = wall_clock64();
 
-    // fixed-order reduction: one thread per row, blocks 0..S-1 in order, all of
-    // a row's loads in flight together
+    // fixed-order reduction over the S slices.  partials is [slice][row], so a
+    // wave's load of one slice covers 64 consecutive rows (coalesced).  Threads
+    // 0..127 sum slices 0..31 of row t, threads 128..255 slices 32..63 (all 32
+    // loads in flight); row total = (slices 0..31) + (slices 32..63).
     {
-        const uint32_t nrows = 3 * nb + 1;
+        const uint32_t nrows = NSUM * nb + 1;
         const uint32_t S = gridDim.x;
-        for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
-            const uint32_t r = (rr == 3 * nb) ? 3 * MAX_BATCH : rr;
-            const double* row = p.partials + (size_t)r * S_CAP;
+        const uint32_t half = tid >> 7, rl = tid & 127u;
+        for (uint32_t rr0 = 0; rr0 < nrows; rr0 += 128) {
+            const uint32_t rr = rr0 + rl;
+            const bool live = rr < nrows;
+            const uint32_t r = (rr == NSUM * nb) ? NSUM * MAX_BATCH : rr;
+            const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = (live && half * 32u + u < S) ? __hip_atomic_load(col + (size_t)u * ROWS_CAP, HG_RLX_AGENT) : 0.0;
             double acc = 0.0;
-            for (uint32_t b0 = 0; b0 < S; b0 += 16) {
-                double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = (b0 + u < S) ? __hip_atomic_load(row + b0 + u, HG_RLX_AGENT) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (b0 + u < S) acc += v[u];
-            }
-            sh.tot[(rr == 3 * nb) ? 3 * sh.bcap : rr] = acc;
+            for (int u = 0; u < 32; ++u) acc += v[u];
+            if (rr0) __syncthreads(); // previous round's exchange buffer is free again
+            if (half == 1) sh.red[rl] = acc;
+            __syncthreads();
+            if (live && half == 0) sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr] = acc + sh.red[rl];
         }
     }
     if (tid == 0) __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[2] = wall_clock64();
 
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
-        for (int r = tid; r < 3 * MAX_BATCH + 1; r += BLOCK) {
+        for (int r = tid; r < NSUM * MAX_BATCH + 1; r += BLOCK) {
             double v = 0.0;
-            if (r < 3 * (int)nb) v = sh.tot[r];
-            if (r == 3 * MAX_BATCH) v = sh.tot[3 * sh.bcap];
+            if (r < NSUM * (int)nb) v = sh.tot[r];
+            if (r == NSUM * MAX_BATCH) v = sh.tot[NSUM * sh.bcap];
             p.sums_out[r] = v;
         }
         return;
@@ -460,8 +488,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     if ((nb == 0 && !pend) || d.error) return;
     const MarkerMeta meta = load_marker_meta(p, d, nb, threadIdx.x);
     stage_rng(p, sh, threadIdx.x);
-    for (int r = threadIdx.x; r < 3 * (int)nb; r += BLOCK) sh.tot[r] = p.sums_out[r];
-    if (threadIdx.x == 0) sh.tot[3 * sh.bcap] = p.sums_out[3 * MAX_BATCH];
+    for (int r = threadIdx.x; r < NSUM * (int)nb; r += BLOCK) sh.tot[r] = p.sums_out[r];
+    if (threadIdx.x == 0) sh.tot[NSUM * sh.bcap] = p.sums_out[NSUM * MAX_BATCH];
     __syncthreads();
     sweep_draw_phase(p, d, nb, sh, meta);
 }

@@ -82,6 +82,10 @@ struct hgibbs_ctx {
     // sweep scratch
     int32_t* order = nullptr;
     uint8_t* adaV = nullptr;
+    double *s_mave = nullptr, *s_mstd = nullptr, *s_bold = nullptr;
+    int32_t* s_ga = nullptr;
+    unsigned long long* dbg = nullptr; // 8 words, device
+    bool debug_timing = false;
     int32_t* cass = nullptr;
     double* tables = nullptr; // 4 * G*K
     uint32_t* mt = nullptr;
@@ -250,6 +254,21 @@ __global__ void k_stats(const unsigned long long* __restrict__ counts, uint32_t 
     mstd[i] = sqrt((double)(N - 1) / (tmp0 + tmp1 + tmp2));
 }
 
+// per-marker metadata in sweep order (one pass per sweep): the draw phase then
+// reads contiguous, order-independent rows
+__global__ void k_gather_meta(const int32_t* __restrict__ order, const double* __restrict__ mave, const double* __restrict__ mstd,
+                              const double* __restrict__ beta, const int32_t* __restrict__ groups, const uint8_t* __restrict__ adaV,
+                              const unsigned long long* __restrict__ counts, double* s_mave, double* s_mstd, double* s_bold, int32_t* s_ga, uint32_t M)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const int m = order[j];
+    s_mave[j] = mave[m];
+    s_mstd[j] = mstd[m];
+    s_bold[j] = beta[m];
+    s_ga[j] = groups[m] | (adaV[m] ? 0x40000000 : 0) | (counts[3ull * m + 2] ? 0x20000000 : 0);
+}
+
 __global__ void k_set_eps(double* eps, const double* __restrict__ src, uint32_t n_local, uint32_t n_pad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,7 +431,9 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
     HIP_TRY(hipMalloc(&h->ticket, 64));
     HIP_TRY(hipMemset(h->ticket, 0, 64));
-    HIP_TRY(hipMalloc(&h->sums, (3 * MAX_BATCH + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->sums, (NSUM * MAX_BATCH + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->dbg, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->dbg, 0, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
     *out = h;
     return 0;
@@ -425,7 +446,7 @@ int hgibbs_destroy(hgibbs_t h)
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
+                    h->adaV, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -484,13 +505,17 @@ static int alloc_problem(hgibbs_ctx* h, uint32_t n_global, uint32_t n_local, uin
     HIP_TRY(hipMalloc(&h->acum, (size_t)M * sizeof(double)));
     HIP_TRY(hipMalloc(&h->order, (size_t)M * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->adaV, (size_t)M));
+    HIP_TRY(hipMalloc(&h->s_mave, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->s_mstd, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->s_bold, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->s_ga, (size_t)M * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->groups, (size_t)M * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(h->beta, 0, (size_t)M * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->comp, 0, (size_t)M * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->acum, 0, (size_t)M * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->groups, 0, (size_t)M * sizeof(int32_t), h->stream));
     const uint32_t nblk_x = h->n_pad / BLOCK_IND;
-    HIP_TRY(hipMalloc(&h->partials, (size_t)(3 * MAX_BATCH + 1) * S_CAP * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->partials, (size_t)ROWS_CAP * S_CAP * sizeof(double)));
     if (ensure_scratch(h, (size_t)nblk_x * 4 + 4096)) return 1;
     h->eps_cur = 0;
     h->have_stats = false;
@@ -784,11 +809,25 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "debug_timing")) {
+        h->debug_timing = value != 0;
     } else if (!std::strcmp(name, "chunk")) {
         h->chunk = (int)value;
     } else {
         return fail("hgibbs_set_option: unknown option '%s'", name);
     }
+    return 0;
+}
+
+/* stage timestamps (100 MHz ticks) of the LAST launch that did work: [0] first
+ * workgroup at loop entry, [1] last arriver past the ticket, [2] partials
+ * reduced, [3] posteriors done, [4] descriptor written.  Diagnostic only. */
+int hgibbs_debug_times(hgibbs_t h, uint64_t* out8)
+{
+    if (!h || !out8) return fail("null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(out8, h->dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->dbg, 0, 16 * sizeof(unsigned long long)));
     return 0;
 }
 
@@ -838,6 +877,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->ticket, 0, 64, h->stream));
+    k_gather_meta<<<(M + 255) / 256, 256, 0, h->stream>>>(h->order, h->mave, h->mstd, h->beta, h->groups, h->adaV, h->counts, h->s_mave, h->s_mstd,
+                                                       h->s_bold, h->s_ga, M);
+    HIP_TRY(hipGetLastError());
 
     const uint32_t cpg = h->cols_per_group;
     const uint32_t ngroups = (h->batch + cpg - 1) / cpg;
@@ -869,6 +911,12 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.acum = h->acum;
     p.cass = h->cass;
     p.K = K;
+    p.GK = G * K;
+    p.s_mave = h->s_mave;
+    p.s_mstd = h->s_mstd;
+    p.s_bold = h->s_bold;
+    p.s_ga = h->s_ga;
+    p.dbg = h->debug_timing ? h->dbg : nullptr;
     p.denom = h->tables;
     p.logpi = h->tables + (size_t)G * K;
     p.hlog = h->tables + (size_t)2 * G * K;
@@ -903,7 +951,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             default: k_sweep_batch<16><<<grid, BLOCK, lds, h->stream>>>(p); break;
             }
             if (h->nranks > 1) {
-                NCCL_TRY(ncclAllReduce(h->sums, h->sums, 3 * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+                NCCL_TRY(ncclAllReduce(h->sums, h->sums, NSUM * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
                 k_sweep_draw<<<1, BLOCK, lds, h->stream>>>(p);
             }
         }

@@ -66,12 +66,16 @@ inline int genotype_at(const uint8_t* col, uint32_t i)
 }
 
 int g_threads = 1; /* >1 only for the cpu_baseline leg of bench.py */
+int g_dot_form = 0; /* 0 = sparse form (plain --bfile, :316-342), 1 = dense LUT form (:1766-1809) */
 
 } // namespace
 
 extern "C" {
 
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+/* which of the reference's two algebraically equal dot forms the sweep uses */
+void orc_set_dot_form(int dense) { g_dot_form = dense ? 1 : 0; }
+double orc_dot_dense(const uint8_t* col, const double* eps, uint32_t N, double mave, double mstd, double* s1_out, double* s2_out);
 
 /* (byte, slot) -> (genotype value, non-missing mask): the two quantities
  * dotp_lut_a / dotp_lut_b tabulate (src/dotp_lut.h:3,1033; src/mk_lut.cpp:24-35,54-65) */
@@ -257,7 +261,8 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
         if (adaV[marker]) {
             for (int i = 1; i <= km1; ++i) denom[i - 1] = dNm1 + sigE_G * cVaI[grp * K + i];
 
-            double num = orc_dot(col, eps, N, mave[marker], mstd[marker]);
+            double num = g_dot_form ? orc_dot_dense(col, eps, N, mave[marker], mstd[marker], nullptr, nullptr)
+                                    : orc_dot(col, eps, N, mave[marker], mstd[marker]);
             num += b * (double)(N - 1);
 
             for (int i = 1; i <= km1; ++i) muk[i] = num / denom[i - 1];

@@ -27,6 +27,7 @@ def load(name="liboracle.so"):
     u64p = C.POINTER(C.c_uint64)
     mtp = C.POINTER(OrcMt)
     L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_dot_form.argtypes = [C.c_int]
     L.orc_decode_byte.argtypes = [C.c_uint8, dp, dp]
     L.orc_bed_counts.argtypes = [u8p, C.c_uint32, u64p, u64p, u64p, u64p]
     L.orc_marker_stats.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, dp, dp]

@@ -134,6 +134,17 @@ def test_chain_vs_oracle_small(oracle, batch):
                          batch=batch, iters=4)
 
 
+def test_chain_vs_oracle_dense_form(oracle):
+    """Same chain against the oracle run with the reference's dense LUT algebra
+    (src/BayesRRm.cpp:1766-1809), the form the HIP kernel accumulates in."""
+    oracle.orc_set_dot_form(1)
+    try:
+        _gpu_sweep_vs_oracle(oracle, M=300, N=2100, G=1, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), groups=None,
+                             batch=48, iters=4, missing_rate=0.03)
+    finally:
+        oracle.orc_set_dot_form(0)
+
+
 def test_chain_vs_oracle_groups(oracle):
     M = 400
     groups = (np.arange(M) % 2).astype(np.int32)
