@@ -1,3 +1,463 @@
-// placeholder until the CLI lands (next commit): keeps `make` green
+// hydra_main.cpp -- `hydra_mi355x`: hydra's command line on top of the C ABI.
+//
+// Drop-in for `hydra --mpibayes bayesMPI --bfile X --pheno P ...`
+// (src/main.cpp:17-195 -> BayesRRm::runMpiGibbs, src/BayesRRm.cpp:933): same
+// flags (src/options.cpp:7-297; defaults src/options.hpp:101-127), same input
+// files (.bed/.bim/.fam, .phen with NA, --groupIndexFile/--groupMixtureFile),
+// same output files and byte layouts (src/BayesRRm.cpp:1071-1083,1299-1309,
+// 2736-2794): <dir>/<name>.csv .bet .cpn .acu .mus.<rank>, and on --save
+// .eps.<rank> .mrk.<rank> .xbet .xcpn (:2802-2838).
+//
+// Not reproduced (out of scope for the hot path): sparse
+// file formats, --restart, covariates, bayesFH/bayesW, marker-sharded MPI.
+// Multi-GPU: one process per GPU (RANK/WORLD_SIZE/LOCAL_RANK in the
+// environment, as torchrun/mpirun export them); individuals are sharded and the
+// ncclUniqueId travels through a file in --mcmc-out-dir.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
-int main() { std::printf("hydra_mi355x: CLI not built yet\n"); return 2; }
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hgibbs.h"
+
+namespace {
+
+struct Options { // src/options.hpp:20-138 (subset that reaches bayesMPI)
+    std::string bayesType, analysisType = "Bayes";
+    std::string bedFile, phenotypeFile, mcmcOutDir, mcmcOutNam, groupIndexFile, groupMixtureFile;
+    unsigned chainLength = 10000, burnin = 5000, thin = 5, save = 10;
+    unsigned seed = 0;
+    bool seedGiven = false;
+    unsigned numberMarkers = 0, numberIndividuals = 0;
+    int shuffleMarkers = 1, syncRate = 1;
+    std::vector<double> S{0.01, 0.001, 0.0001};
+    bool readFromBedFile = false;
+    int batch = 0, cpg = 0; // tuning knobs of this build (not hydra's)
+};
+
+[[noreturn]] void fatal(const std::string& m)
+{
+    std::fprintf(stderr, "\n%s\n", m.c_str());
+    std::exit(1);
+}
+
+// Gadget::Tokenizer::getTokens, src/gadgets.cpp:12-22
+std::vector<std::string> tokens(const std::string& str, const std::string& sep)
+{
+    std::vector<std::string> out;
+    std::string::size_type b = str.find_first_not_of(sep);
+    while (b != std::string::npos) {
+        std::string::size_type e = str.find_first_of(sep, b);
+        if (e == std::string::npos) e = str.length();
+        out.push_back(str.substr(b, e - b));
+        b = str.find_first_not_of(sep, e);
+    }
+    return out;
+}
+
+Options parse(int argc, const char* argv[])
+{
+    Options o;
+    auto need = [&](int& i) -> const char* {
+        if (i + 1 >= argc) fatal(std::string("missing value after ") + argv[i]);
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--mpibayes" || a == "--bayesType") { // --bayesType: alias (it is the option-file key, options.cpp:353)
+            o.analysisType = "RAM";
+            o.bayesType = need(i);
+        } else if (a == "--bfile") {
+            o.readFromBedFile = true;
+            o.bedFile = need(i);
+        } else if (a == "--pheno") {
+            o.phenotypeFile = tokens(need(i), ",").at(0);
+        } else if (a == "--mcmc-out-dir") o.mcmcOutDir = need(i);
+        else if (a == "--mcmc-out-name") o.mcmcOutNam = need(i);
+        else if (a == "--shuf-mark") o.shuffleMarkers = std::atoi(need(i));
+        else if (a == "--sync-rate") o.syncRate = std::atoi(need(i));
+        else if (a == "--number-markers") o.numberMarkers = (unsigned)std::atoi(need(i));
+        else if (a == "--number-individuals") o.numberIndividuals = (unsigned)std::atoi(need(i));
+        else if (a == "--chain-length") o.chainLength = (unsigned)std::atoi(need(i));
+        else if (a == "--burn-in") o.burnin = (unsigned)std::atoi(need(i));
+        else if (a == "--seed") {
+            o.seed = (unsigned)std::atoi(need(i));
+            o.seedGiven = true;
+        } else if (a == "--thin") o.thin = (unsigned)std::atoi(need(i));
+        else if (a == "--save") o.save = (unsigned)std::atoi(need(i));
+        else if (a == "--S") {
+            o.S.clear();
+            for (const std::string& t : tokens(need(i), " ,")) o.S.push_back(std::stod(t));
+        } else if (a == "--groupIndexFile") o.groupIndexFile = need(i);
+        else if (a == "--groupMixtureFile") o.groupMixtureFile = need(i);
+        else if (a == "--batch") o.batch = std::atoi(need(i));
+        else if (a == "--cols-per-group") o.cpg = std::atoi(need(i));
+        else if (a == "--sparse-dir" || a == "--sparse-basename" || a == "--restart" || a == "--covariates" ||
+                 a == "--bed-to-sparse" || a == "--sparse-sync" || a == "--bed-sync" || a == "--failure" || a == "--quad_points")
+            fatal("FATAL  : option " + a + " belongs to a part of hydra this build does not reproduce (SURVEY.md section 2)");
+        else
+            fatal("\nError: invalid option \"" + a + "\".\n"); // options.cpp:292-295
+    }
+    if (!o.seedGiven) o.seed = (unsigned)std::time(nullptr); // options.hpp:105
+    if (o.analysisType == "RAM") {                           // options.cpp:303-326
+        if (o.mcmcOutDir.empty()) fatal("FATAL  : --mcmc-out-dir is mandatory with --mpibayes");
+        if (o.mcmcOutNam.empty()) fatal("FATAL  : --mcmc-out-name is mandatory with --mpibayes");
+    }
+    return o;
+}
+
+size_t count_fam(const std::string& path, std::vector<std::string>* ids)
+{
+    std::ifstream in(path);
+    if (!in) fatal("Error: can not open the file [" + path + "] to read.");
+    std::string fid, pid, dad, mom, sex, phen;
+    size_t n = 0;
+    std::map<std::string, int> seen;
+    while (in >> fid >> pid >> dad >> mom >> sex >> phen) { // data.cpp:1454
+        const std::string id = fid + ":" + pid;
+        if (!seen.emplace(id, 1).second) fatal("Error: Duplicate individual ID found: \"" + fid + "\t" + pid + "\".");
+        if (ids) ids->push_back(id);
+        ++n;
+    }
+    return n;
+}
+
+size_t count_bim(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) fatal("Error: can not open the file [" + path + "] to read.");
+    std::string id, a1, a2;
+    unsigned chr, pos;
+    float gpos;
+    size_t n = 0;
+    while (in >> chr >> id >> gpos >> pos >> a1 >> a2) ++n; // data.cpp:1484
+    return n;
+}
+
+// Data::readPhenotypeFile(phenFile), src/data.cpp:1840-1882: lines whose FID:IID
+// is in the .fam are taken in FILE order; "NA" marks a dropped individual.
+void read_phen(const std::string& path, const std::vector<std::string>& fam_ids, std::vector<double>& y,
+               std::vector<uint8_t>& keep)
+{
+    std::ifstream in(path);
+    if (!in) fatal("Error: can not open the phenotype file [" + path + "] to read.");
+    std::map<std::string, int> idx;
+    for (size_t i = 0; i < fam_ids.size(); ++i) idx[fam_ids[i]] = (int)i;
+    keep.assign(fam_ids.size(), 1);
+    y.clear();
+    std::string line;
+    size_t lineno = 0;
+    while (std::getline(in, line)) {
+        std::vector<std::string> col = tokens(line, " \t");
+        if (col.size() < 3) continue;
+        if (!idx.count(col[0] + ":" + col[1])) continue;
+        if (lineno >= keep.size()) break;
+        if (col[2] != "NA") y.push_back(std::atof(col[2].c_str()));
+        else keep[lineno] = 0; // NAsInds.push_back(line)
+        ++lineno;
+    }
+    if (lineno != fam_ids.size()) fatal("FATAL  : phenotype file covers " + std::to_string(lineno) + " of " + std::to_string(fam_ids.size()) + " individuals");
+}
+
+std::vector<int32_t> read_groups(const std::string& path) // data.cpp:1940-1958
+{
+    std::ifstream in(path);
+    if (!in) fatal("Error: can not open the group file [" + path + "] to read. Use the --groupIndexFile option!");
+    std::vector<int32_t> g;
+    int v;
+    while (in >> v) g.push_back(v);
+    return g;
+}
+
+std::vector<std::vector<double>> read_mS(const std::string& path) // data.cpp:1963-2004
+{
+    std::ifstream in(path);
+    if (!in) fatal("Error: can not open the mixture file [" + path + "] to read. Use the --groupMixtureFile option!");
+    std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::vector<std::string> rows = tokens(text, ";");
+    std::vector<std::vector<double>> mS;
+    size_t ncomp = 0;
+    for (const std::string& r : rows) {
+        std::vector<std::string> t = tokens(r, ",");
+        // a trailing newline after the last ';' group is not a group
+        bool blank = true;
+        for (char ch : r)
+            if (!std::isspace((unsigned char)ch)) blank = false;
+        if (blank) continue;
+        if (ncomp == 0) ncomp = t.size();
+        if (t.size() != ncomp) fatal("FATAL  : all group mixture should have the same number of components");
+        std::vector<double> row{0.0};
+        for (const std::string& x : t) {
+            const double mix = std::stod(x);
+            if (mix <= 0.0) fatal("FATAL  : mixture value can only be strictly positive");
+            row.push_back(mix);
+        }
+        mS.push_back(row);
+    }
+    return mS;
+}
+
+void hg_check(int rc, const char* what)
+{
+    if (rc) fatal(std::string("FATAL  : ") + what + ": " + hgibbs_last_error());
+}
+
+void pwrite_at(FILE* f, long off, const void* p, size_t n)
+{
+    if (std::fseek(f, off, SEEK_SET) != 0 || std::fwrite(p, 1, n, f) != n) fatal("FATAL  : short write on an output file");
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+int main(int argc, const char* argv[])
+{
+    if (argc < 2) {
+        std::cerr << " \nDid you forget to give the input parameters?\n" << std::endl;
+        return 1;
+    }
+    Options opt = parse(argc, argv);
+    if (!(opt.bayesType == "bayesMPI" && opt.analysisType == "RAM")) {
+        std::cerr << "\n Error: Wrong analysis requested: " << opt.analysisType << " + " << opt.bayesType
+                  << " (this build reproduces --mpibayes bayesMPI)" << std::endl;
+        return 0; // the reference catches the throw and still returns 0 (main.cpp:179-189)
+    }
+    if (!opt.readFromBedFile) fatal("FATAL: either go for BED, SPARSE or BOTH (this build reads --bfile)");
+    if ((opt.groupIndexFile.empty()) != (opt.groupMixtureFile.empty()))
+        fatal("FATAL   : you need to activate both --groupIndexFile and --groupMixtureFile");
+    if (opt.syncRate > 1)
+        std::printf("WARNING: --sync-rate %d ignored: individuals are sharded, every marker sees the current residual\n", opt.syncRate);
+
+    const char* e;
+    const int rank = (e = std::getenv("RANK")) ? std::atoi(e) : 0;
+    const int nranks = (e = std::getenv("WORLD_SIZE")) ? std::atoi(e) : 1;
+    const int local_rank = (e = std::getenv("LOCAL_RANK")) ? std::atoi(e) : rank;
+
+    // ---- inputs (main.cpp:69-70,88; BayesRRm.cpp:969-997) -------------------
+    std::vector<std::string> fam_ids;
+    const size_t numInds = count_fam(opt.bedFile + ".fam", &fam_ids);
+    const size_t numSnps = count_bim(opt.bedFile + ".bim");
+    std::vector<double> y;
+    std::vector<uint8_t> keep;
+    read_phen(opt.phenotypeFile, fam_ids, y, keep);
+    const unsigned numNAs = (unsigned)(numInds - y.size());
+
+    if (opt.numberIndividuals == 0) fatal("FATAL  : opt.numberIndividuals is zero! Set it via --number-individuals in call.");
+    if (opt.numberMarkers == 0) fatal("FATAL  : opt.numberMarkers is zero! Set it via --number-markers in call.");
+    if (opt.numberIndividuals != numInds) fatal("FATAL  : --number-individuals does not match the .fam file");
+    unsigned Mtot = opt.numberMarkers;
+    if (Mtot > numSnps) fatal("FATAL  : --number-markers exceeds the .bim file");
+    if (Mtot < numSnps && rank == 0) std::printf("INFO   : Option passed to process only %d markers!\n", Mtot);
+    const unsigned Ntot = (unsigned)numInds - numNAs;
+    if (rank == 0) {
+        if (numNAs)
+            std::printf("WARNING: opt.numberIndividuals set to %zu but will be adjusted to %zu - %u = %u due to NAs in phenotype file.\n",
+                        numInds, numInds, numNAs, Ntot);
+        std::printf("INFO   : Full dataset includes Mtot=%d markers and Ntot=%d individuals.\n", Mtot, (int)numInds);
+    }
+
+    std::vector<int32_t> groups;
+    std::vector<std::vector<double>> mS;
+    if (!opt.groupIndexFile.empty()) {
+        groups = read_groups(opt.groupIndexFile);
+        mS = read_mS(opt.groupMixtureFile);
+        if (groups.size() < Mtot) fatal("FATAL  : group file covers fewer markers than --number-markers");
+        groups.resize(Mtot);
+    } else {
+        std::vector<double> row{0.0};
+        for (double v : opt.S) {
+            if (v <= 0.0) fatal("FATAL  : mixture value can only be strictly positive");
+            row.push_back(v);
+        }
+        mS.push_back(row);
+    }
+    const int G = (int)mS.size(), K = (int)mS[0].size();
+    std::vector<double> mS_flat;
+    for (auto& r : mS) mS_flat.insert(mS_flat.end(), r.begin(), r.end());
+
+    // --thin/--save adjustment, BayesRRm.cpp:1058-1066
+    if (opt.save < opt.thin) {
+        opt.save = opt.thin;
+        if (rank == 0) std::printf("WARNING: opt.save was lower that opt.thin ; opt.save reset to opt.thin (%d)\n", opt.thin);
+    }
+    if (opt.save % opt.thin != 0) {
+        opt.save = (opt.save / opt.thin) * opt.thin;
+        if (rank == 0) std::printf("         opt.save reset to %d, the closest multiple of opt.thin (%d)\n", opt.save, opt.thin);
+    }
+
+    struct stat sb;
+    if (stat(opt.mcmcOutDir.c_str(), &sb) != 0 && rank == 0)
+        if (std::system(("mkdir -p " + opt.mcmcOutDir).c_str()) != 0) fatal("FATAL  : can not create --mcmc-out-dir");
+    const std::string base = opt.mcmcOutDir + "/" + opt.mcmcOutNam;
+
+    // ---- device -------------------------------------------------------------
+    hgibbs_t dev = nullptr;
+    hg_check(hgibbs_create(local_rank, &dev), "hgibbs_create");
+    if (nranks > 1) {
+        uint8_t id[128];
+        const std::string idf = base + ".ncclid";
+        if (rank == 0) {
+            hg_check(hgibbs_comm_unique_id(id), "hgibbs_comm_unique_id");
+            FILE* f = std::fopen((idf + ".tmp").c_str(), "wb");
+            if (!f || std::fwrite(id, 1, 128, f) != 128) fatal("FATAL  : can not write " + idf);
+            std::fclose(f);
+            std::rename((idf + ".tmp").c_str(), idf.c_str());
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = std::fopen(idf.c_str(), "rb")); ++tries)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || std::fread(id, 1, 128, f) != 128) fatal("FATAL  : can not read " + idf);
+            std::fclose(f);
+        }
+        hg_check(hgibbs_comm_init(dev, nranks, rank, id), "hgibbs_comm_init");
+        if (rank == 0) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(200));
+            std::remove(idf.c_str());
+        }
+    }
+    if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
+    if (opt.cpg) hg_check(hgibbs_set_option(dev, "cols_per_group", opt.cpg), "cols_per_group");
+
+    // ---- genotypes: Data::load_data_from_bed_file, data.cpp:671-739 -----------
+    const double tl0 = now_s();
+    const size_t snpLenByt = (numInds + 3) / 4;
+    std::vector<uint8_t> bed;
+    {
+        std::ifstream in(opt.bedFile + ".bed", std::ios::binary);
+        if (!in) fatal("Error: can not open the file [" + opt.bedFile + ".bed] to read.");
+        unsigned char magic[3];
+        in.read((char*)magic, 3);
+        if (!in || magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01) fatal("FATAL  : " + opt.bedFile + ".bed is not a SNP-major PLINK bed");
+        bed.resize((size_t)Mtot * snpLenByt);
+        in.read((char*)bed.data(), (std::streamsize)bed.size());
+        if ((size_t)in.gcount() != bed.size()) fatal("FATAL  : " + opt.bedFile + ".bed is shorter than M x ceil(N/4)");
+    }
+    // individuals sharded in multiples of 4 of the KEPT rows
+    const unsigned per = ((Ntot + nranks - 1) / nranks + 3) / 4 * 4;
+    const unsigned lo = std::min(Ntot, rank * per), hi = std::min(Ntot, (rank + 1) * per);
+    hg_check(hgibbs_load_bed(dev, bed.data(), snpLenByt, (uint32_t)numInds, Mtot, numNAs ? keep.data() : nullptr, lo, hi, Ntot),
+             "hgibbs_load_bed");
+    std::printf("INFO   : rank %3d took %.3f seconds to load  %lu bytes  =>  BW = %7.3f GB/s\n", rank, now_s() - tl0,
+                (unsigned long)bed.size(), (double)bed.size() * 1e-9 / (now_s() - tl0));
+    std::vector<uint8_t>().swap(bed);
+
+    hydra_model_desc md{};
+    md.seed = opt.seed + (unsigned)0 * 1000; // every rank replicates rank 0's stream (BayesRRm.cpp:1228 with rank = 0)
+    md.shuffle = opt.shuffleMarkers;
+    md.G = G;
+    md.K = K;
+    md.groups = groups.empty() ? nullptr : groups.data();
+    md.mS = mS_flat.data();
+    hydra_chain_t chain = nullptr;
+    hg_check(hydra_chain_create(dev, &md, y.data(), &chain), "hydra_chain_create");
+
+    // ---- outputs (rank 0 writes the shared files) ----------------------------
+    FILE *outf = nullptr, *betf = nullptr, *cpnf = nullptr, *acuf = nullptr, *xbetf = nullptr, *xcpnf = nullptr;
+    auto open_trunc = [&](const std::string& p) {
+        FILE* f = std::fopen(p.c_str(), "wb+");
+        if (!f) fatal("FATAL  : can not create " + p);
+        return f;
+    };
+    if (rank == 0) {
+        outf = open_trunc(base + ".csv");
+        betf = open_trunc(base + ".bet");
+        cpnf = open_trunc(base + ".cpn");
+        acuf = open_trunc(base + ".acu");
+        xbetf = open_trunc(base + ".xbet");
+        xcpnf = open_trunc(base + ".xcpn");
+        for (FILE* f : {betf, xbetf, cpnf, xcpnf, acuf}) pwrite_at(f, 0, &Mtot, sizeof(unsigned)); // :1302-1309
+    }
+    FILE* musf = open_trunc(base + ".mus." + std::to_string(rank));
+    FILE* epsf = open_trunc(base + ".eps." + std::to_string(rank));
+    FILE* mrkf = open_trunc(base + ".mrk." + std::to_string(rank));
+
+    std::vector<double> beta(Mtot), acum(Mtot), eps(hi - lo);
+    std::vector<int32_t> comp(Mtot);
+    std::vector<double> sigmaG(G);
+    std::vector<int32_t> m0(G);
+    std::vector<char> buff(50000);
+    unsigned n_thinned_saved = 0;
+    const double t_all = now_s();
+
+    for (unsigned iteration = 0; iteration < opt.chainLength; ++iteration) {
+        const double t0 = now_s();
+        hg_check(hydra_chain_iterate(chain), "hydra_chain_iterate");
+        const double t1 = now_s();
+        double sigmaE = 0, mu = 0;
+        hydra_chain_state(chain, &sigmaE, &mu, sigmaG.data(), nullptr, m0.data(), nullptr, nullptr);
+        double sg = 0;
+        long m0s = 0;
+        for (int g = 0; g < G; ++g) {
+            sg += sigmaG[g];
+            m0s += m0[g];
+        }
+        if (rank % 10 == 0) { // :2713-2722 (sync columns are zero: there is no marker-sharded sync in this build)
+            std::printf("RESULT : it %4d, rank %4d: proc = %9.3f s, sync = %9.3f (%9.3f + %9.3f), n_sync = %8d (%8d + %8d) (%7.3f / %7.3f), "
+                        "sigmaG = %15.10f, sigmaE = %15.10f, betasq = %15.10f, m0 = %10ld\n",
+                        iteration, rank, t1 - t0, 0.0, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, sg, sigmaE, 0.0, m0s);
+            std::fflush(stdout);
+        }
+
+        if (iteration % opt.thin == 0) { // :2736-2794
+            hg_check(hgibbs_get_beta(dev, beta.data(), comp.data(), acum.data()), "hgibbs_get_beta");
+            if (rank == 0) {
+                const int len = hydra_chain_csv_line(chain, iteration, buff.data(), buff.size());
+                pwrite_at(outf, (long)n_thinned_saved * len, buff.data(), (size_t)len);
+                long off = sizeof(unsigned) + (long)n_thinned_saved * (sizeof(unsigned) + (long)Mtot * sizeof(double));
+                pwrite_at(betf, off, &iteration, sizeof(unsigned));
+                pwrite_at(acuf, off, &iteration, sizeof(unsigned));
+                pwrite_at(betf, off + sizeof(unsigned), beta.data(), (size_t)Mtot * sizeof(double));
+                pwrite_at(acuf, off + sizeof(unsigned), acum.data(), (size_t)Mtot * sizeof(double));
+                off = sizeof(unsigned) + (long)n_thinned_saved * (sizeof(unsigned) + (long)Mtot * sizeof(int));
+                pwrite_at(cpnf, off, &iteration, sizeof(unsigned));
+                pwrite_at(cpnf, off + sizeof(unsigned), comp.data(), (size_t)Mtot * sizeof(int));
+            }
+            long off = (long)n_thinned_saved * (sizeof(unsigned) + sizeof(double));
+            pwrite_at(musf, off, &iteration, sizeof(unsigned));
+            pwrite_at(musf, off + sizeof(unsigned), &mu, sizeof(double));
+            n_thinned_saved += 1;
+        }
+
+        if (iteration > 0 && iteration % opt.save == 0) { // :2802-2838 (no .rng text dump, no tarball)
+            hg_check(hgibbs_get_residual(dev, eps.data()), "hgibbs_get_residual");
+            const unsigned nloc = hi - lo;
+            pwrite_at(epsf, 0, &iteration, sizeof(unsigned));
+            pwrite_at(epsf, sizeof(unsigned), &nloc, sizeof(unsigned));
+            pwrite_at(epsf, 2 * sizeof(unsigned), eps.data(), (size_t)nloc * sizeof(double));
+            pwrite_at(mrkf, 0, &iteration, sizeof(unsigned));
+            pwrite_at(mrkf, sizeof(unsigned), &Mtot, sizeof(unsigned));
+            pwrite_at(mrkf, 2 * sizeof(unsigned), hydra_chain_order(chain), (size_t)Mtot * sizeof(int));
+            if (rank == 0) {
+                hg_check(hgibbs_get_beta(dev, beta.data(), comp.data(), nullptr), "hgibbs_get_beta");
+                pwrite_at(xbetf, sizeof(unsigned), &iteration, sizeof(unsigned));
+                pwrite_at(xcpnf, sizeof(unsigned), &iteration, sizeof(unsigned));
+                pwrite_at(xbetf, 2 * sizeof(unsigned), beta.data(), (size_t)Mtot * sizeof(double));
+                pwrite_at(xcpnf, 2 * sizeof(unsigned), comp.data(), (size_t)Mtot * sizeof(int));
+            }
+        }
+    }
+    if (rank == 0)
+        std::printf("INFO   : rank %4d, time to process the data: %.3f sec, with %.3f (%.3f, %.3f) = %4.1f%% spent on allred (%d, %d)\n", rank,
+                    now_s() - t_all, 0.0, 0.0, 0.0, 0.0, 0, 0);
+    for (FILE* f : {outf, betf, cpnf, acuf, xbetf, xcpnf, musf, epsf, mrkf})
+        if (f) std::fclose(f);
+    hydra_chain_destroy(chain);
+    hgibbs_destroy(dev);
+    return 0;
+}

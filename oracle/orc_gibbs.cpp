@@ -232,6 +232,65 @@ struct orc_model {
     const double* cVaI;     /* G*K, col 0 = 0 */
 };
 
+/* a5-a7 for ONE marker given its dot product `num` (x_j'eps, before the
+ * `+= beta*(N-1)` of :1855): src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921.
+ * Returns 0, or -1 on the reference's "logL overflow" abort (:1910-1913). */
+int orc_marker_draw(double num, double beta_old, uint32_t N, int K, const double* cVa_g, const double* cVaI_g,
+                    const double* estPi_g, double sigmaE, double sigmaG_g, orc_mt* rng,
+                    double* beta_new, int* component, double* acum_out)
+{
+    const double dNm1 = (double)(N - 1);
+    const int km1 = K - 1;
+    double denom[16], muk[16], logL[16];
+    const double sigE_G = sigmaE / sigmaG_g;
+    const double sigG_E = sigmaG_g / sigmaE;
+    const double i_2sigE = 1.0 / (2.0 * sigmaE);
+    muk[0] = 0.0;
+    for (int i = 1; i <= km1; ++i) denom[i - 1] = dNm1 + sigE_G * cVaI_g[i];
+    num += beta_old * (double)(N - 1);
+    for (int i = 1; i <= km1; ++i) muk[i] = num / denom[i - 1];
+    for (int i = 0; i < K; ++i) logL[i] = log(estPi_g[i]);
+    for (int i = 1; i < 1 + km1; ++i)
+        logL[i] = logL[i] - 0.5 * log(sigG_E * dNm1 * cVa_g[i] + 1.0) + muk[i] * num * i_2sigE;
+
+    double prob = orc_unif_rng(rng);
+
+    double acum = 0.0;
+    bool big = false;
+    for (int i = 1; i < K; ++i)
+        if (fabs(logL[i] - logL[0]) > 700.0) big = true;
+    if (big) {
+        acum = 0.0;
+    } else {
+        double s = 0.0;
+        for (int i = 0; i < K; ++i) s += exp(logL[i] - logL[0]);
+        acum = 1.0 / s;
+    }
+    *acum_out = acum;
+
+    for (int k = 0; k < K; ++k) {
+        if (prob <= acum || k == km1) {
+            if (k == 0) *beta_new = 0.0;
+            else *beta_new = orc_norm_rng(rng, muk[k], sigmaE / denom[k - 1]);
+            *component = k;
+            return 0;
+        } else {
+            if (k + 1 >= K) return -1;
+            bool big2 = false;
+            for (int l = k + 1; l < K; ++l)
+                if (fabs(logL[l] - logL[k + 1]) > 700.0) big2 = true;
+            if (big2) {
+                acum += 0.0;
+            } else {
+                double s = 0.0;
+                for (int l = 0; l < K; ++l) s += exp(logL[l] - logL[k + 1]);
+                acum += 1.0 / s;
+            }
+        }
+    }
+    return -1;
+}
+
 /* Returns the number of markers with deltaBeta != 0.  cass is G*K, zeroed by the caller
  * (src/BayesRRm.cpp:1697).  Returns -1 on the reference's "logL overflow" abort (:1910-1913). */
 long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
@@ -242,11 +301,7 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
                double* eps, double* beta, int* components, double* acum_out, int* cass,
                orc_mt* rng)
 {
-    const double dNm1 = (double)(N - 1);
-    const int km1 = K - 1;
-    std::vector<double> denom(km1 > 0 ? km1 : 1), muk(K), logL(K);
     long nnz = 0;
-    muk[0] = 0.0;
 
     for (uint32_t j = 0; j < M; ++j) {
         const int marker = order[j];
@@ -254,58 +309,15 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
         const uint8_t* col = bed + (uint64_t)marker * stride;
         double b = beta[marker];
 
-        const double sigE_G = sigmaE / sigmaG[grp];
-        const double sigG_E = sigmaG[grp] / sigmaE;
-        const double i_2sigE = 1.0 / (2.0 * sigmaE);
-
         if (adaV[marker]) {
-            for (int i = 1; i <= km1; ++i) denom[i - 1] = dNm1 + sigE_G * cVaI[grp * K + i];
-
             double num = g_dot_form ? orc_dot_dense(col, eps, N, mave[marker], mstd[marker], nullptr, nullptr)
                                     : orc_dot(col, eps, N, mave[marker], mstd[marker]);
-            num += b * (double)(N - 1);
-
-            for (int i = 1; i <= km1; ++i) muk[i] = num / denom[i - 1];
-            for (int i = 0; i < K; ++i) logL[i] = log(estPi[grp * K + i]);
-            for (int i = 1; i < 1 + km1; ++i)
-                logL[i] = logL[i] - 0.5 * log(sigG_E * dNm1 * cVa[grp * K + i] + 1.0) + muk[i] * num * i_2sigE;
-
-            double prob = orc_unif_rng(rng);
-
-            double acum = 0.0;
-            bool big = false;
-            for (int i = 1; i < K; ++i)
-                if (fabs(logL[i] - logL[0]) > 700.0) big = true;
-            if (big) {
-                acum = 0.0;
-            } else {
-                double s = 0.0;
-                for (int i = 0; i < K; ++i) s += exp(logL[i] - logL[0]);
-                acum = 1.0 / s;
-            }
-            acum_out[marker] = acum;
-
-            for (int k = 0; k < K; ++k) {
-                if (prob <= acum || k == km1) {
-                    if (k == 0) beta[marker] = 0.0;
-                    else beta[marker] = orc_norm_rng(rng, muk[k], sigmaE / denom[k - 1]);
-                    cass[grp * K + k] += 1;
-                    components[marker] = k;
-                    break;
-                } else {
-                    if (k + 1 >= K) return -1;
-                    bool big2 = false;
-                    for (int l = k + 1; l < K; ++l)
-                        if (fabs(logL[l] - logL[k + 1]) > 700.0) big2 = true;
-                    if (big2) {
-                        acum += 0.0;
-                    } else {
-                        double s = 0.0;
-                        for (int l = 0; l < K; ++l) s += exp(logL[l] - logL[k + 1]);
-                        acum += 1.0 / s;
-                    }
-                }
-            }
+            int k = 0;
+            if (orc_marker_draw(num, b, N, K, cVa + (size_t)grp * K, cVaI + (size_t)grp * K, estPi + (size_t)grp * K, sigmaE,
+                                sigmaG[grp], rng, &beta[marker], &k, &acum_out[marker]))
+                return -1;
+            cass[grp * K + k] += 1;
+            components[marker] = k;
         } else {
             beta[marker] = 0.0;
             acum_out[marker] = 1.0;

@@ -41,6 +41,7 @@ def load(name="liboracle.so"):
     L.orc_sweep.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, dp, dp, C.c_int, C.c_int, ip, dp, dp,
                             ip, C.c_double, dp, dp, u8p, dp, dp, ip, dp, ip, mtp]
     L.orc_sweep.restype = C.c_long
+    L.orc_marker_draw.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_int, dp, dp, dp, C.c_double, C.c_double, mtp, dp, ip, dp]
     L.orc_chain_create.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, dp, C.c_int, C.c_int, ip, dp,
                                    C.c_uint32, C.c_int]
     L.orc_chain_create.restype = C.c_void_p

@@ -206,3 +206,119 @@ def test_synth_bed_matches_host_hash():
     full = synth.unpack_bed_columns(dev.get_bed(), N)
     part = synth.unpack_bed_columns(dev2.get_bed(), 503)
     assert np.array_equal(part, full[:, 500:])
+
+
+# ---------------------------------------------------------------------------
+# the CLI: hydra's flags in, hydra's files out (src/BayesRRm.cpp:2736-2794)
+# ---------------------------------------------------------------------------
+import os
+import struct
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "hydra_amd", "bin", "hydra_mi355x")
+
+
+def _read_bet(path, M, dtype):
+    raw = open(path, "rb").read()
+    assert struct.unpack("<I", raw[:4])[0] == M  # first word = Mtot (postproc/beta_converter.cpp:33-46)
+    item = np.dtype(dtype).itemsize
+    rec = 4 + M * item
+    assert (len(raw) - 4) % rec == 0
+    its, vals = [], []
+    for k in range((len(raw) - 4) // rec):
+        off = 4 + k * rec
+        its.append(struct.unpack("<I", raw[off:off + 4])[0])
+        vals.append(np.frombuffer(raw[off + 4:off + rec], dtype=dtype))
+    return its, np.array(vals)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_cli_end_to_end_files_match_oracle(oracle, tmp_path, grouped):
+    M, N, iters = 120, 403, 6
+    geno = synth.make_genotypes(M, N, seed=31, missing_rate=0.02)
+    y, _ = synth.make_phenotype(geno, seed=32, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+    na_rows = [3, 100, 101, 402]
+    prefix = str(tmp_path / "data")
+    synth.write_plink(prefix, bed, N, y=y, na_rows=na_rows)
+    out = str(tmp_path / "out")
+    cmd = [EXE, "--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--mcmc-out-dir", out,
+           "--mcmc-out-name", "run", "--number-individuals", str(N), "--number-markers", str(M), "--chain-length", str(iters),
+           "--thin", "1", "--save", "2", "--seed", "1222", "--shuf-mark", "1"]
+    if grouped:
+        groups = (np.arange(M) % 2).astype(np.int32)
+        np.savetxt(prefix + ".group", groups, fmt="%d")
+        open(prefix + ".mS", "w").write("0.001,0.01,0.1;0.001,0.01,0.1\n")
+        cmd += ["--groupIndexFile", prefix + ".group", "--groupMixtureFile", prefix + ".mS"]
+        mS = np.array([[0.0, 0.001, 0.01, 0.1], [0.0, 0.001, 0.01, 0.1]])
+    else:
+        cmd += ["--S", "0.0001,0.001,0.01"]
+        groups, mS = None, np.array([[0.0, 0.0001, 0.001, 0.01]])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RESULT : it    0, rank    0: proc =" in r.stdout
+
+    keep = np.ones(N, dtype=np.uint8)
+    keep[na_rows] = 0
+    geno_k = geno[:, keep == 1]
+    ref = orc.Chain(oracle, synth.pack_bed_columns(geno_k), int(keep.sum()), y[keep == 1], groups=groups, mS=mS, seed=1222)
+    its, betas = _read_bet(out + "/run.bet", M, np.float64)
+    _, comps = _read_bet(out + "/run.cpn", M, np.int32)
+    _, acus = _read_bet(out + "/run.acu", M, np.float64)
+    csv = open(out + "/run.csv").read().splitlines()
+    assert its == list(range(iters)) and len(csv) == iters
+    mus = open(out + "/run.mus.0", "rb").read()
+    assert len(mus) == iters * 12
+    for it in range(iters):
+        ref.iterate()
+        assert np.array_equal(comps[it], ref.arr("components"))
+        assert close(betas[it], ref.arr("beta")) and close(acus[it], ref.arr("acum"))
+        got = [float(x) for x in csv[it].split(",")]
+        want = [float(x) for x in ref.csv_line(it).split(",")]
+        assert len(csv[it]) + 1 == len(ref.csv_line(it)) and close(got, want, 1e-9)
+        k, mu = struct.unpack("<Id", mus[12 * it:12 * it + 12])
+        assert k == it and close(mu, ref.mu)
+    # --save 2: last checkpoint taken at iteration 4
+    eps_raw = open(out + "/run.eps.0", "rb").read()
+    it_s, n_s = struct.unpack("<II", eps_raw[:8])
+    assert (it_s, n_s) == (4, int(keep.sum())) and len(eps_raw) == 8 + 8 * n_s
+    xb = open(out + "/run.xbet", "rb").read()
+    assert struct.unpack("<II", xb[:8]) == (M, 4) and close(np.frombuffer(xb[8:], dtype=np.float64), betas[4])
+
+
+def test_full_size_properties_c2():
+    """BASELINE config 2 (N=50 000, M=100 000) through size-independent
+    properties: (1) residual identity eps + X beta == y - mu after the sweep
+    (round trip through the update operator), (2) counts add up, (3) batch
+    width does not change a single bit of the chain."""
+    N, M = 50000, 100000
+    res = []
+    for batch in (64, 17):
+        dev = capi.Device(0)
+        dev.set_option("batch", batch)
+        dev.synth_bed(N, M, seed=42)
+        rng = np.random.default_rng(1)
+        y = rng.normal(size=N)
+        dev.set_residual(y)
+        for j, b in zip(rng.choice(M, 300, replace=False), rng.normal(0, 0.04, 300)):
+            dev.update_marker(int(j), -float(b))
+        y = dev.get_residual()
+        ch = capi.Chain(dev, y, seed=1222)
+        ys = dev.get_residual()  # centred / scaled phenotype as the chain holds it
+        for _ in range(2):
+            ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st = ch.state()
+        eps = dev.get_residual()
+        res.append((beta, comp, eps, st))
+        assert st["cass"].sum() == M and st["m0"][0] == (comp != 0).sum()
+        assert np.all((beta != 0) == (comp != 0)) and np.all((acum >= 0) & (acum <= 1.0 + 1e-12))
+        # add X beta back onto eps with the product's own update operator
+        for j in np.flatnonzero(beta):
+            dev.update_marker(int(j), float(beta[j]))
+        back = dev.get_residual()
+        assert np.max(np.abs(back - (ys - st["mu"]))) < 1e-8
+        dev.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][3]["sigmaE"] == res[1][3]["sigmaE"]

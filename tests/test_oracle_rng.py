@@ -1,0 +1,126 @@
+"""The oracle's RNG restatement against every pin available without Boost:
+MT19937 known answer (C++ standard), the Ziggurat tables inside the reference's
+ELF (golden fixture + live bytes when /root/reference is present), distribution
+laws (KS tests vs scipy), and regression vectors."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+from scipy import stats
+
+import orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_mt19937_known_answer(oracle):
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(g, 5489)
+    for _ in range(9999):
+        oracle.orc_rng_u32(g)
+    assert oracle.orc_rng_u32(g) == 4123659995  # [rand.predef] 10000th invocation
+
+
+def _oracle_tables(oracle):
+    out = []
+    for which in range(4):
+        n = C.c_int()
+        p = oracle.orc_zig_table(which, C.byref(n))
+        out.append(np.ctypeslib.as_array(p, shape=(n.value,)).copy())
+    return out
+
+
+def test_ziggurat_tables_match_reference_elf_fixture(oracle):
+    gold = np.load(os.path.join(GOLD, "boost_ziggurat_tables.npz"))
+    for got, key in zip(_oracle_tables(oracle), ("normal_x", "normal_y", "exp_x", "exp_y")):
+        assert got.tobytes() == gold[key].tobytes(), key  # bit for bit
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/hydra"), reason="reference checkout not present")
+def test_ziggurat_tables_match_live_elf_bytes(oracle):
+    d = open("/root/reference/src/hydra", "rb").read()
+    for got, (off, n) in zip(_oracle_tables(oracle), ((0xD7FC0, 129), (0xD83E0, 129), (0xD6F80, 257), (0xD77A0, 257))):
+        assert got.tobytes() == d[off:off + 8 * n]
+
+
+def test_product_tables_equal_oracle_tables(oracle):
+    """The product carries its own copy of the generated header."""
+    root = os.path.dirname(GOLD[:-len("/golden")])
+    a = open(os.path.join(root, "oracle", "zig_tables.h")).read().replace("ORC_ZIG_", "X_")
+    b = open(os.path.join(root, "hydra_amd", "csrc", "hg_zig_tables.h")).read().replace("HG_ZIG_", "X_")
+    assert a == b
+
+
+def test_distribution_laws(oracle):
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(g, 4242)
+    n = 60000
+    z = np.array([oracle.orc_rng_norm(g, 1.5, 4.0) for _ in range(n)])
+    assert stats.kstest(z, "norm", args=(1.5, 2.0)).pvalue > 1e-3
+    e = np.array([oracle.orc_rng_exp(g, 2.5) for _ in range(n)])
+    assert stats.kstest(e, "expon", args=(0, 1 / 2.5)).pvalue > 1e-3
+    for a in (0.3, 1.0, 2.5, 40.0):
+        x = np.array([oracle.orc_rng_gamma(g, a, 1.7) for _ in range(n)])
+        assert stats.kstest(x, "gamma", args=(a, 0, 1.7)).pvalue > 1e-3, a
+    b = np.array([oracle.orc_rng_beta(g, 2.0, 5.0) for _ in range(n)])
+    assert stats.kstest(b, "beta", args=(2.0, 5.0)).pvalue > 1e-3
+    # inv_scaled_chisq(nu, s2) = 1/Gamma(nu/2, scale 2/(nu s2))  (src/distributions_boost.cpp:89-107)
+    nu, s2 = 9.0, 0.4
+    v = np.array([oracle.orc_rng_inv_scaled_chisq(g, nu, s2) for _ in range(n)])
+    assert stats.kstest(1.0 / v, "gamma", args=(nu / 2, 0, 2.0 / (nu * s2))).pvalue > 1e-3
+    u = np.array([oracle.orc_rng_unif(g) for _ in range(n)])
+    assert u.min() >= 0 and u.max() < 1 and stats.kstest(u, "uniform").pvalue > 1e-3
+
+
+def test_normal_tail_and_wedge_paths_are_exercised(oracle):
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(g, 7)
+    z = np.array([oracle.orc_rng_norm(g, 0.0, 1.0) for _ in range(400000)])
+    tail = np.abs(z) > 3.4426198558966523
+    assert 0.5 < tail.sum() / (400000 * 2 * stats.norm.sf(3.4426198558966523)) < 1.5
+
+
+def test_int_float_pair_layout(oracle):
+    """u1 low 8 bits = bucket, high 24 bits + 29 bits of u2 = 53-bit uniform
+    (the layout found in the ELF's generate_int_float_pair): the
+    first normal draw can be recomputed by hand from the first two outputs."""
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(g, 99)
+    u1, u2 = oracle.orc_rng_u32(g), oracle.orc_rng_u32(g)
+    gold = np.load(os.path.join(GOLD, "boost_ziggurat_tables.npz"))
+    r = ((u1 >> 8) * 2.0 ** -24 + (u2 & 0x1FFFFFFF)) * 2.0 ** -29
+    bucket = u1 & 0xFF
+    i, sign = bucket >> 1, (bucket & 1) * 2 - 1
+    x = r * gold["normal_x"][i]
+    oracle.orc_rng_seed(g, 99)
+    z = oracle.orc_rng_norm(g, 0.0, 1.0)
+    if x < gold["normal_x"][i + 1]:
+        assert z == x * sign
+    else:
+        pytest.skip("first draw left the fast path for this seed")
+
+
+def test_regression_vectors(oracle):
+    gold = np.load(os.path.join(GOLD, "rng_kat.npz"))
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(g, 1222)
+    assert np.array_equal(gold["u32"], np.array([oracle.orc_rng_u32(g) for _ in range(16)], dtype=np.uint32))
+    oracle.orc_rng_seed(g, 1222)
+    assert np.array_equal(gold["unif"], np.array([oracle.orc_rng_unif(g) for _ in range(16)]))
+    assert np.array_equal(gold["unif"], gold["u32"] / 4294967296.0)
+    oracle.orc_rng_seed(g, 1222)
+    assert np.array_equal(gold["norm"], np.array([oracle.orc_rng_norm(g, 0.5, 2.0) for _ in range(4000)]))
+    oracle.orc_rng_seed(g, 1222)
+    assert np.array_equal(gold["exp"], np.array([oracle.orc_rng_exp(g, 1.5) for _ in range(2000)]))
+    for name, shape in (("gamma_lt1", 0.3), ("gamma_eq1", 1.0), ("gamma_gt1", 7.25)):
+        oracle.orc_rng_seed(g, 1222)
+        assert np.array_equal(gold[name], np.array([oracle.orc_rng_gamma(g, shape, 2.0) for _ in range(500)]))
+    oracle.orc_rng_seed(g, 1222)
+    assert np.array_equal(gold["beta"], np.array([oracle.orc_rng_beta(g, 1.0, 1.0) for _ in range(100)]))
+    oracle.orc_rng_seed(g, 1222)
+    v = np.arange(40, dtype=np.int32)
+    oracle.orc_rng_shuffle(g, orc.iptr(v), 40)
+    assert sorted(v) == list(range(40))
+    assert np.array_equal(v, gold["shuffle40_gcc11"])  # libstdc++ 11 algorithm (toolchain dependent, src/BayesRRm.cpp:1688)
