@@ -196,7 +196,7 @@ def main():
             "config": {"workload": "BayesRR %s: N=%d individuals x M=%d markers, K=%d mixture, G=%d groups, "
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
-                       "N": N, "M": M, "batch": args.batch or 32, "nnz_updates_per_iter": nnz / K,
+                       "N": N, "M": M, "batch": args.batch or 64, "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": launches / K, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -101,10 +101,11 @@ struct hgibbs_ctx {
     double* beta_host = nullptr;    // pinned, M doubles (lazy)
 
     // options
-    uint32_t batch = 32;
+    uint32_t batch = 64;
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
+    bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
     hgibbs_sweep_stats stats{};
 };
@@ -474,7 +475,7 @@ int hgibbs_comm_init(hgibbs_t h, int nranks, int rank, const void* id128)
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("hgibbs_comm_init: bad rank %d of %d", rank, nranks);
     h->nranks = nranks;
     h->rank = rank;
-    if (nranks == 1) return 0;
+    if (nranks == 1 && !id128) return 0; // a 1-rank communicator is only built on request (tests of the split path)
     HIP_TRY(hipSetDevice(h->device));
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
@@ -614,7 +615,7 @@ static int compute_stats(hgibbs_ctx* h)
     if (h->have_stats) return 0;
     k_counts<<<h->M, BLOCK, 0, h->stream>>>(h->bed, h->stride, h->n_pad, h->n_local, h->counts, h->M);
     HIP_TRY(hipGetLastError());
-    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->counts, h->counts, (size_t)h->M * 3, ncclUint64, ncclSum, h->comm, h->stream));
+    if (h->comm) NCCL_TRY(ncclAllReduce(h->counts, h->counts, (size_t)h->M * 3, ncclUint64, ncclSum, h->comm, h->stream));
     k_stats<<<(h->M + 255) / 256, 256, 0, h->stream>>>(h->counts, h->n_global, h->mave, h->mstd, h->M);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -677,7 +678,7 @@ int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
     k_reduce_eps<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], h->n_pad, h->scratch);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 2, h->sums);
     HIP_TRY(hipGetLastError());
-    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 2, ncclDouble, ncclSum, h->comm, h->stream));
+    if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 2, ncclDouble, ncclSum, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (sum) *sum = h->scratch_host[0];
@@ -722,7 +723,7 @@ int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num)
     k_dot_one<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, marker, h->eps[h->eps_cur], h->scratch);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 4, h->sums);
     HIP_TRY(hipGetLastError());
-    if (h->nranks > 1) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 4, ncclDouble, ncclSum, h->comm, h->stream));
+    if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 4, ncclDouble, ncclSum, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host + 4, h->mave + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host + 5, h->mstd + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -809,6 +810,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "force_split")) {
+        h->force_split = value != 0;
     } else if (!std::strcmp(name, "debug_timing")) {
         h->debug_timing = value != 0;
     } else if (!std::strcmp(name, "chunk")) {
@@ -931,7 +934,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
-    p.sums_out = (h->nranks > 1) ? h->sums : nullptr;
+    const bool split = h->nranks > 1 || h->force_split;
+    p.sums_out = split ? h->sums : nullptr;
 
     const uint32_t ntg = h->n_pad / BLOCK_IND;
     const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
@@ -950,8 +954,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             case 8: k_sweep_batch<8><<<grid, BLOCK, lds, h->stream>>>(p); break;
             default: k_sweep_batch<16><<<grid, BLOCK, lds, h->stream>>>(p); break;
             }
-            if (h->nranks > 1) {
-                NCCL_TRY(ncclAllReduce(h->sums, h->sums, NSUM * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+            if (split) {
+                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, NSUM * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
                 k_sweep_draw<<<1, BLOCK, lds, h->stream>>>(p);
             }
         }

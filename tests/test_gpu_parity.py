@@ -177,6 +177,31 @@ def test_batch_width_does_not_change_the_chain():
         assert o[2]["sigmaE"] == outs[0][2]["sigmaE"] and np.array_equal(o[2]["rng_x"], outs[0][2]["rng_x"])
 
 
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_split_path_equals_fused_path(with_comm):
+    """The multi-GPU structure (local sums -> all-reduce -> replicated draw, three
+    launches per batch) run on one rank -- with a 1-rank RCCL communicator so that
+    the ncclAllReduce calls execute -- gives the fused kernel's chain bit for bit."""
+    bed, y = make_case(400, 2500, seed=17)
+    outs = []
+    for split in (False, True):
+        dev = capi.Device(0)
+        if split and with_comm:
+            dev.comm_init(1, 0, capi.Device.unique_id())
+        dev.load_bed(bed, 2500)
+        dev.set_option("batch", 48)
+        dev.set_option("force_split", 1 if split else 0)
+        ch = capi.Chain(dev, y, seed=9)
+        for _ in range(3):
+            ch.iterate()
+        outs.append((dev.get_beta(), dev.get_residual(), ch.state()))
+        dev.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2]["sigmaE"] == outs[1][2]["sigmaE"] and np.array_equal(outs[0][2]["rng_x"], outs[1][2]["rng_x"])
+
+
 def test_na_phenotype_rows_are_dropped(oracle):
     M, N = 60, 1000
     bed, y = make_case(M, N, seed=21)
