@@ -71,6 +71,7 @@ def cpu_baseline(dev, y_local_is_full, y, N, M, mS, groups, sample_markers, thre
         threads = 1
     L = orc.load(lib_name)
     L.orc_set_threads(threads)
+    L.orc_set_dot_form(2)  # the reference's dense LUT/AVX2 loop structure incl. its bookkeeping passes
     ms = min(sample_markers, M)
     bed = dev.get_bed(0, ms)
     g = None if groups is None else np.ascontiguousarray(groups[:ms])
@@ -79,8 +80,11 @@ def cpu_baseline(dev, y_local_is_full, y, N, M, mS, groups, sample_markers, thre
     t0 = time.perf_counter()
     ch.iterate()
     dt = time.perf_counter() - t0
+    L.orc_set_dot_form(0)
     return {"value": ms / dt, "unit": "markers/s", "cores": threads, "kind": "port",
-            "sample": "first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s" % (ms, M, N, lib_name)}
+            "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
+                      "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, "
+                      "-O3 -march=native -fopenmp" % (ms, M, N, lib_name)}
 
 
 def main():
@@ -205,7 +209,7 @@ def main():
                          "sweep_ms_per_iter": sweep_ms / K},
         }
         if not args.no_cpu_baseline and world == 1:
-            threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+            threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU
             sample = args.cpu_sample or max(64, min(M, int(4.0e9 / max(1, N))))
             out["cpu_baseline"] = cpu_baseline(dev, True, y, N, M, mS, groups, sample, threads)
         else:

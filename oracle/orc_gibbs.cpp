@@ -37,6 +37,10 @@
 
 #include "orc_rng.h"
 
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -66,7 +70,13 @@ inline int genotype_at(const uint8_t* col, uint32_t i)
 }
 
 int g_threads = 1; /* >1 only for the cpu_baseline leg of bench.py */
-int g_dot_form = 0; /* 0 = sparse form (plain --bfile, :316-342), 1 = dense LUT form (:1766-1809) */
+int g_dot_form = 0; /* 0 = sparse form (plain --bfile, :316-342), 1 = dense LUT form (:1766-1809),
+                       2 = dense LUT form with the reference's loop structure (LUT gathers, AVX2, OpenMP
+                           reduction, and its bookkeeping passes): the "restated hydra AVX path" timed
+                           by bench.py's cpu_baseline leg (fallback 2) */
+double g_lut_a[1024], g_lut_b[1024];
+bool g_lut_ready = false;
+std::vector<double> g_tmpEps, g_deltaEps, g_dEpsSum;
 
 } // namespace
 
@@ -74,7 +84,7 @@ extern "C" {
 
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 /* which of the reference's two algebraically equal dot forms the sweep uses */
-void orc_set_dot_form(int dense) { g_dot_form = dense ? 1 : 0; }
+void orc_set_dot_form(int form) { g_dot_form = (form < 0 || form > 2) ? 0 : form; }
 double orc_dot_dense(const uint8_t* col, const double* eps, uint32_t N, double mave, double mstd, double* s1_out, double* s2_out);
 
 /* (byte, slot) -> (genotype value, non-missing mask): the two quantities
@@ -192,6 +202,101 @@ void orc_update(const uint8_t* col, double* eps, uint32_t N, double mave, double
     }
 }
 
+
+/* ---- "restated hydra AVX path" (cpu_baseline only) -------------------------
+ * dot: src/BayesRRm.cpp:1770-1809 -- per byte two 4-wide LUT gathers, eps load,
+ * mul, add, mul, add, OpenMP reduction over bytes, scalar tail for N%4.
+ * update: :1976-2010 (deltaEps from the LUT), :2022 (dEpsSum += deltaEps),
+ * :2471 (eps = tmpEps + dEpsSum), :2478 (tmpEps = eps), :2481 (dEpsSum = 0). */
+static void lut_init()
+{
+    if (g_lut_ready) return;
+    for (int byte = 0; byte < 256; ++byte)
+        for (int s = 0; s < 4; ++s) {
+            int g = decode_code((byte >> (2 * s)) & 3u);
+            g_lut_a[4 * byte + s] = g < 0 ? 0.0 : (double)g;
+            g_lut_b[4 * byte + s] = g < 0 ? 0.0 : 1.0;
+        }
+    g_lut_ready = true;
+}
+
+double orc_dot_hydra_avx(const uint8_t* col, const double* eps, uint32_t N, double mave, double mstd)
+{
+    lut_init();
+    const int fullb = (int)(N / 4);
+    double s1 = 0.0, s2 = 0.0;
+#if defined(__AVX2__)
+    double r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+#pragma omp parallel num_threads(g_threads)
+    {
+        __m256d vsum1 = _mm256_setzero_pd(), vsum2 = _mm256_setzero_pd();
+#pragma omp for schedule(static) nowait
+        for (int ii = 0; ii < fullb; ++ii) {
+            __m256d p4c1 = _mm256_loadu_pd(&g_lut_a[col[ii] * 4]);
+            __m256d p4c2 = _mm256_loadu_pd(&g_lut_b[col[ii] * 4]);
+            __m256d p4eps = _mm256_loadu_pd(&eps[ii * 4]);
+            __m256d p4sum = _mm256_mul_pd(p4c2, p4eps);
+            vsum2 = _mm256_add_pd(vsum2, p4sum);
+            p4sum = _mm256_mul_pd(p4sum, p4c1);
+            vsum1 = _mm256_add_pd(vsum1, p4sum);
+        }
+        double t1[4], t2[4];
+        _mm256_storeu_pd(t1, vsum1);
+        _mm256_storeu_pd(t2, vsum2);
+#pragma omp critical
+        for (int k = 0; k < 4; ++k) {
+            r1[k] += t1[k];
+            r2[k] += t2[k];
+        }
+    }
+    s1 = r1[0] + r1[1] + r1[2] + r1[3];
+    s2 = r2[0] + r2[1] + r2[2] + r2[3];
+#else
+#pragma omp parallel for reduction(+ : s1, s2) num_threads(g_threads) schedule(static)
+    for (int ii = 0; ii < fullb; ++ii)
+        for (int k = 0; k < 4; ++k) {
+            double c1 = g_lut_a[col[ii] * 4 + k], c2 = g_lut_b[col[ii] * 4 + k];
+            s1 += c1 * (c2 * eps[ii * 4 + k]);
+            s2 += c2 * eps[ii * 4 + k];
+        }
+#endif
+    for (uint32_t i = (uint32_t)fullb * 4u; i < N; ++i) {
+        int idx = col[fullb] * 4 + (int)(i - (uint32_t)fullb * 4u);
+        s1 += g_lut_a[idx] * (g_lut_b[idx] * eps[i]);
+        s2 += g_lut_b[idx] * eps[i];
+    }
+    return mstd * (s1 - mave * s2);
+}
+
+void orc_update_hydra(const uint8_t* col, double* eps, uint32_t N, double mave, double mstd, double dbeta)
+{
+    lut_init();
+    if (g_tmpEps.size() != N) {
+        g_tmpEps.assign(eps, eps + N);
+        g_deltaEps.assign(N, 0.0);
+        g_dEpsSum.assign(N, 0.0);
+    }
+    double* tmpEps = g_tmpEps.data();
+    double* deltaEps = g_deltaEps.data();
+    double* dEpsSum = g_dEpsSum.data();
+    const double sigdb = mstd * dbeta;
+    const int nb = (int)((N + 3) / 4);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int ii = 0; ii < nb; ++ii)
+        for (int k = 0; k < 4; ++k) {
+            uint32_t i = (uint32_t)ii * 4u + (uint32_t)k;
+            if (i < N) deltaEps[i] = (g_lut_a[col[ii] * 4 + k] - mave) * g_lut_b[col[ii] * 4 + k] * sigdb;
+        }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)N; ++i) dEpsSum[i] += deltaEps[i];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)N; ++i) eps[i] = tmpEps[i] + dEpsSum[i];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)N; ++i) tmpEps[i] = eps[i];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)N; ++i) dEpsSum[i] = 0.0;
+}
+
 /* a3: src/BayesRRm.cpp:371-388 */
 void orc_center_and_scale(double* vec, uint32_t N)
 {
@@ -302,6 +407,11 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
                orc_mt* rng)
 {
     long nnz = 0;
+    if (g_dot_form == 2) { // :1700 tmpEps = epsilon, dEpsSum = 0 (:1544)
+        g_tmpEps.assign(eps, eps + N);
+        g_deltaEps.assign(N, 0.0);
+        g_dEpsSum.assign(N, 0.0);
+    }
 
     for (uint32_t j = 0; j < M; ++j) {
         const int marker = order[j];
@@ -310,8 +420,9 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
         double b = beta[marker];
 
         if (adaV[marker]) {
-            double num = g_dot_form ? orc_dot_dense(col, eps, N, mave[marker], mstd[marker], nullptr, nullptr)
-                                    : orc_dot(col, eps, N, mave[marker], mstd[marker]);
+            double num = g_dot_form == 2   ? orc_dot_hydra_avx(col, eps, N, mave[marker], mstd[marker])
+                         : g_dot_form == 1 ? orc_dot_dense(col, eps, N, mave[marker], mstd[marker], nullptr, nullptr)
+                                           : orc_dot(col, eps, N, mave[marker], mstd[marker]);
             int k = 0;
             if (orc_marker_draw(num, b, N, K, cVa + (size_t)grp * K, cVaI + (size_t)grp * K, estPi + (size_t)grp * K, sigmaE,
                                 sigmaG[grp], rng, &beta[marker], &k, &acum_out[marker]))
@@ -327,7 +438,8 @@ long orc_sweep(const uint8_t* bed, uint64_t stride, uint32_t N, uint32_t M,
         b = beta[marker];
         const double deltaBeta = betaOld - b;
         if (deltaBeta != 0.0) {
-            orc_update(col, eps, N, mave[marker], mstd[marker], deltaBeta);
+            if (g_dot_form == 2) orc_update_hydra(col, eps, N, mave[marker], mstd[marker], deltaBeta);
+            else orc_update(col, eps, N, mave[marker], mstd[marker], deltaBeta);
             ++nnz;
         }
     }
