@@ -42,6 +42,22 @@ def algorithmic_bytes(n_local, M, nnz):
     return M * (col + 8 * n_local) + nnz * 16 * n_local + 16 * n_local + 20 * M
 
 
+def measured_traffic(N, batch, world):
+    """HBM-side bytes per k_sweep_batch launch from the committed rocprofv3 PMC
+    passes (profiles/r*_pmc_traffic.json: FETCH_SIZE doubled + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md), when they were taken on this
+    workload; None otherwise."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("N") == N and d.get("batch") == batch and world == 1:
+            return float(d["traffic_bytes_per_launch"])
+    return None
+
+
 def make_phenotype_on_device(dev, n_global, M, rank_rows, seed, h2=0.5, causal_frac=0.01):
     """y = X_std beta + e built with the product's own residual-update operator:
     eps <- e, then eps += beta_j x_j for the causal markers.  Returns y (all
@@ -203,7 +219,7 @@ def main():
                        "N": N, "M": M, "batch": args.batch or 64, "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": launches / K, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or 64, world),
                          "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
                          "sweep_ms_per_iter": sweep_ms / K},
