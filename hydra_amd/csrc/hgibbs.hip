@@ -531,23 +531,28 @@ int hgibbs_load_bed(hgibbs_t h, const uint8_t* bed_host, uint64_t stride_in, uin
     if (stride_in < ((uint64_t)n_total + 3) / 4) return fail("hgibbs_load_bed: stride_in %llu < ceil(%u/4)", (unsigned long long)stride_in, n_total);
     HIP_TRY(hipSetDevice(h->device));
     const uint32_t n_local = row_end - row_begin;
+    // validate everything before anything is allocated on the handle
+    std::vector<uint32_t> kept;
+    if (!keep_host) {
+        if (row_end > n_total) return fail("hgibbs_load_bed: row_end %u > n_total %u", row_end, n_total);
+        if (row_begin & 3u) return fail("hgibbs_load_bed: row_begin %u must be a multiple of 4", row_begin);
+    } else {
+        kept.reserve(n_total);
+        for (uint32_t i = 0; i < n_total; ++i)
+            if (keep_host[i]) kept.push_back(i);
+        if (row_end > kept.size()) return fail("hgibbs_load_bed: row_end %u > kept individuals %zu", row_end, kept.size());
+    }
+    if (n_global < 2) return fail("hgibbs_load_bed: n_global must be at least 2");
     if (alloc_problem(h, n_global, n_local, M, row_begin)) return 1;
     HIP_TRY(hipMemsetAsync(h->bed, 0x55, (size_t)M * h->stride, h->stream));
 
     if (!keep_host) {
-        if (row_end > n_total) return fail("hgibbs_load_bed: row_end %u > n_total %u", row_end, n_total);
-        if (row_begin & 3u) return fail("hgibbs_load_bed: row_begin %u must be a multiple of 4", row_begin);
         const size_t width = ((size_t)n_local + 3) / 4;
         HIP_TRY(hipMemcpy2DAsync(h->bed, h->stride, bed_host + (row_begin >> 2), stride_in, width, M, hipMemcpyHostToDevice, h->stream));
         k_fix_padding<<<(M + 255) / 256, 256, 0, h->stream>>>(h->bed, h->stride, n_local, M);
         HIP_TRY(hipGetLastError());
     } else {
         // NA rows dropped: build the kept-row index list, then gather on the device in slabs of columns
-        std::vector<uint32_t> kept;
-        kept.reserve(n_total);
-        for (uint32_t i = 0; i < n_total; ++i)
-            if (keep_host[i]) kept.push_back(i);
-        if (row_end > kept.size()) return fail("hgibbs_load_bed: row_end %u > kept individuals %zu", row_end, kept.size());
         uint32_t* d_idx = nullptr;
         HIP_TRY(hipMalloc(&d_idx, (size_t)n_local * sizeof(uint32_t)));
         HIP_TRY(hipMemcpyAsync(d_idx, kept.data() + row_begin, (size_t)n_local * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));

@@ -347,3 +347,117 @@ def test_full_size_properties_c2():
         dev.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert res[0][3]["sigmaE"] == res[1][3]["sigmaE"]
+
+
+# ---------------------------------------------------------------------------
+# edge cases of the model and of the data shapes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [2, 3, 8])
+def test_mixture_sizes(oracle, K):
+    mS = np.array([[0.0] + [10.0 ** (-(K - 1 - k)) for k in range(1, K)]])
+    _gpu_sweep_vs_oracle(oracle, M=150, N=700, G=1, mS=mS, groups=None, batch=64, iters=4)
+
+
+def test_too_many_components_is_an_error():
+    bed, y = make_case(10, 50, seed=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, 50)
+    with pytest.raises(capi.HgError):
+        capi.Chain(dev, y, mS=np.array([[0.0] + [0.1] * 9]))
+
+
+def test_many_groups_uses_global_tables(oracle):
+    """G*K > 64: hyper tables are read from global memory instead of LDS."""
+    M, G = 360, 20
+    groups = (np.arange(M) % G).astype(np.int32)
+    mS = np.tile(np.array([[0.0, 0.001, 0.01, 0.1]]), (G, 1))
+    _gpu_sweep_vs_oracle(oracle, M=M, N=900, G=G, mS=mS, groups=groups, batch=64, iters=4)
+
+
+def test_group_frozen_out_and_empty_group(oracle):
+    """A group whose markers all fall into component 0 is frozen (sigmaG = 0,
+    adaV = 0, src/BayesRRm.cpp:2534-2542): its markers then take no RNG draw
+    (:1923-1926).  Group 2 has no markers at all (:1239-1240, :2528)."""
+    M, N = 90, 600
+    rng = np.random.default_rng(4)
+    geno = synth.make_genotypes(M, N, seed=40, missing_rate=0.01)
+    X = synth.standardize(geno)
+    y = X[:, :30] @ rng.normal(0, 0.3, 30) + rng.normal(size=N) * 0.5  # only group 0 carries signal
+    groups = np.where(np.arange(M) < M - 4, 0, 1).astype(np.int32)  # group 1: four markers without signal
+    mS = np.tile(np.array([[0.0, 1e-5, 1e-4, 1e-3]]), (3, 1))
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=2, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=2, shuffle=1)
+    frozen = False
+    for it in range(25):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st = ch.state()
+        assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta")) and close(acum, ref.arr("acum"))
+        assert close(st["sigmaG"], ref.arr("sigmaG")) and st["sigmaG"][2] == 0.0
+        frozen = frozen or (ref.arr("sigmaG")[1] == 0.0)
+    assert frozen, "test data did not freeze group 1; pick another seed"
+    assert np.all(acum[groups == 1] == 1.0) and np.all(beta[groups == 1] == 0.0)
+
+
+@pytest.mark.parametrize("N,M", [(5, 3), (64, 1), (4096, 2), (4097, 9), (12289, 70)])
+def test_ragged_shapes(oracle, N, M):
+    rng = np.random.default_rng(N)
+    geno = rng.integers(0, 3, size=(M, N)).astype(np.uint8)
+    geno[:, 0], geno[:, 1] = 0, 2  # polymorphic
+    if N > 8:
+        geno[:, 5] = 3
+    y = rng.normal(size=N)
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, seed=8)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.Chain(dev, y, seed=8)
+    for _ in range(3):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, _ = dev.get_beta()
+        assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
+    assert close(dev.get_residual(), ref.arr("eps"))
+
+
+@pytest.mark.parametrize("missing_rate,shuffle", [(0.0, 0), (0.3, 1)])
+def test_missingness_extremes_and_no_shuffle(oracle, missing_rate, shuffle):
+    M, N = 200, 1300
+    bed, y = make_case(M, N, seed=50, missing_rate=missing_rate)
+    ref = orc.Chain(oracle, bed, N, y, seed=2, shuffle=shuffle)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.Chain(dev, y, seed=2, shuffle=shuffle)
+    for _ in range(4):
+        ref.iterate()
+        ch.iterate()
+    if not shuffle:
+        assert np.array_equal(ch.order(), np.arange(M))
+    beta, comp, _ = dev.get_beta()
+    assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
+
+
+def test_argument_errors_are_reported():
+    dev = capi.Device(0)
+    with pytest.raises(capi.HgError):
+        dev.set_residual(np.zeros(0))  # no data loaded
+    bed, y = make_case(8, 40, seed=2)
+    with pytest.raises(capi.HgError):
+        dev.load_bed(bed, 40, row_begin=2, row_end=40)  # shard must start on a byte boundary
+    dev.load_bed(bed, 40)
+    with pytest.raises(capi.HgError):
+        dev.load_bed(bed, 40)  # already loaded
+    with pytest.raises(capi.HgError):
+        dev.dot_marker(8)
+    with pytest.raises(capi.HgError):
+        dev.set_option("batch", 100000)
+    ch = capi.Chain(dev, y)
+    st = ch.state()
+    rng = capi.RngState()
+    with pytest.raises(capi.HgError):  # order outside [0, M)
+        dev.sweep(np.array([0, 1, 2, 3, 4, 5, 6, 99], dtype=np.int32), st["sigmaE"], st["sigmaG"], st["estPi"],
+                  np.ones(8, dtype=np.uint8), rng)
