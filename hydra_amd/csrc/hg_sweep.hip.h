@@ -33,6 +33,7 @@ struct SweepShared {
     double* tot;       // 3*bcap + 1 reduced sums
     double* thr;       // [bcap][K-1]
     double* muk;       // [bcap][K]
+    double* logl;      // [bcap][K]
     double* bold;      // [bcap]
     double* mave;
     double* mstd;
@@ -53,7 +54,7 @@ __host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, i
     n += 2 * 130 * 8;
     n += (size_t)BLOCK_WAVES * (NSUM * cpg + 1) * 8;
     n += (size_t)(NSUM * bcap + 1) * 8;
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)bcap * K * 8 + (size_t)3 * bcap * 8;
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)3 * bcap * 8;
     n += (size_t)2 * bcap * 4 + 16 + ((bcap + 15) & ~15u);
     n += (size_t)4 * HT_LDS * 8 + 128 * 8;
     return (n + 15) & ~(size_t)15;
@@ -71,6 +72,7 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NSUM * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
+    sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.mave = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.mstd = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
@@ -167,45 +169,37 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             double num = dp;
             num += mm.bold * p.n_minus_1;
 
-            double logL[MAX_K];
             const bool staged = p.GK <= HT_LDS;
             const double* den = (staged ? sh.htab : p.denom) + (size_t)mm.grp * K;
             const double* lpi = (staged ? sh.htab + HT_LDS : p.logpi) + (size_t)mm.grp * K;
             const double* hlg = (staged ? sh.htab + 2 * HT_LDS : p.hlog) + (size_t)mm.grp * K;
-            logL[0] = lpi[0];
+            sh.logl[tid * K] = lpi[0];
             sh.muk[tid * K] = 0.0;
             for (int k = 1; k < K; ++k) {
                 double mk = num / den[k];
                 sh.muk[tid * K + k] = mk;
-                logL[k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
-            }
-            // cumulative thresholds of the component walk (:1883-1921)
-            double acum;
-            bool big = false;
-            for (int k = 1; k < K; ++k)
-                if (fabs(logL[k] - logL[0]) > 700.0) big = true;
-            if (big) {
-                acum = 0.0;
-            } else {
-                double s = 0.0;
-                for (int k = 0; k < K; ++k) s += exp(logL[k] - logL[0]);
-                acum = 1.0 / s;
-            }
-            sh.thr[tid * (K - 1)] = acum;
-            for (int k = 0; k + 2 < K; ++k) {
-                bool big2 = false;
-                for (int l = k + 1; l < K; ++l)
-                    if (fabs(logL[l] - logL[k + 1]) > 700.0) big2 = true;
-                if (big2) {
-                    acum += 0.0;
-                } else {
-                    double s = 0.0;
-                    for (int l = 0; l < K; ++l) s += exp(logL[l] - logL[k + 1]);
-                    acum += 1.0 / s;
-                }
-                sh.thr[tid * (K - 1) + k + 1] = acum;
+                sh.logl[tid * K + k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
             }
         }
+    }
+    __syncthreads();
+    // increments of the component walk (:1883-1921), one thread per (marker, component):
+    // q[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)
+    for (uint32_t it = tid; it < nb * (uint32_t)(K - 1); it += BLOCK) {
+        const uint32_t j = it / (uint32_t)(K - 1), kk = it % (uint32_t)(K - 1);
+        if (!sh.ada[j]) continue;
+        const double* L = sh.logl + j * K;
+        const double base = L[kk];
+        bool big = false;
+        for (int l = (kk ? (int)kk : 1); l < K; ++l)
+            if (fabs(L[l] - base) > 700.0) big = true;
+        double q = 0.0;
+        if (!big) {
+            double sum = 0.0;
+            for (int l = 0; l < K; ++l) sum += exp(L[l] - base);
+            q = 1.0 / sum;
+        }
+        sh.thr[j * (K - 1) + kk] = q;
     }
     __syncthreads();
     if (p.dbg && tid == 0) p.dbg[3] = wall_clock64();
@@ -233,8 +227,15 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                 const uint32_t u = mt_temper(sh.mt[pos + jeff]);
                 const double prob = (double)u * (1.0 / 4294967296.0);
                 k = K - 1;
-                for (int kk = K - 2; kk >= 0; --kk)
-                    if (prob <= sh.thr[j * (K - 1) + kk]) k = kk; // ends at the FIRST kk that accepts
+                double acum = 0.0; // acum_k = q_0 + ... + q_k, added in the reference's order
+                bool found = false;
+                for (int kk = 0; kk + 1 < K; ++kk) {
+                    acum = kk ? acum + sh.thr[j * (K - 1) + kk] : sh.thr[j * (K - 1)];
+                    if (!found && prob <= acum) {
+                        k = kk;
+                        found = true;
+                    }
+                }
             }
             const bool event = valid && (ada ? (k != 0 || bold != 0.0) : (bold != 0.0));
             const unsigned long long em = __ballot(event);
@@ -302,6 +303,10 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
                 p.dbg[4] = wall_clock64();
                 for (int i = 0; i < 4; ++i) p.dbg[8 + i] += p.dbg[i + 1] - p.dbg[i];
+                p.dbg[13] += p.dbg[6] - p.dbg[5]; // last arriver: entry -> loop done
+                p.dbg[14] += p.dbg[7] - p.dbg[6]; // last arriver: loop done -> drained
+                p.dbg[16] += p.dbg[1] - p.dbg[7]; // last arriver: drained -> past ticket
+                p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
                 p.dbg[12] += naccept;
                 p.dbg[15] += 1;
             }
@@ -344,7 +349,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
     if (!p.sums_out) stage_rng(p, sh, tid);
     if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[0] = wall_clock64();
+    const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
+    unsigned long long t_loop = 0ull;
     double a1[CPG], a2[CPG], sall = 0.0;
 #pragma unroll
     for (int c = 0; c < CPG; ++c) a1[c] = a2[c] = 0.0;
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
                 }
             }
         }
+        t_loop = p.dbg ? wall_clock64() : 0ull;
         // one cross-lane reduction per launch
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
     __syncthreads();
+    const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
         sh.flags[0] = (t == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
@@ -434,7 +443,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     if (!sh.flags[0]) return;
 
     // ---- last-arriving workgroup ---------------------------------------------
-    if (p.dbg && tid == 0) p.dbg[1] = wall_clock64();
+    if (p.dbg && tid == 0) {
+        p.dbg[1] = wall_clock64();
+        p.dbg[5] = t_entry;
+        p.dbg[6] = t_loop;
+        p.dbg[7] = t_drain;
+    }
 
     // fixed-order reduction over the S slices.  partials is [slice][row], so a
     // wave's load of one slice covers 64 consecutive rows (coalesced).  Threads

@@ -8,18 +8,21 @@ import bench
 cfg, batch, cpg = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 N, M, G, mS = bench.CONFIGS[cfg]
 if len(sys.argv) > 4: M = int(sys.argv[4])
+slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 dev = capi.Device(0)
 dev.set_option("batch", batch); dev.set_option("cols_per_group", cpg); dev.set_option("debug_timing", 1)
+if slices: dev.set_option("slices", slices)
 dev.synth_bed(N, M, seed=42)
 y = bench.make_phenotype_on_device(dev, N, M, (0, N), seed=43)
 ch = capi.Chain(dev, y, mS=np.array(mS))
 L = capi.lib(); L.hgibbs_debug_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 for it in range(3):
     ch.iterate()
-    t = (C.c_uint64 * 16)(); L.hgibbs_debug_times(dev.h, t)
+    t = (C.c_uint64 * 24)(); L.hgibbs_debug_times(dev.h, t)
     t = [x for x in t]
     st = dev.sweep_stats()
     print(cfg, "it", it, "kern_us %.1f" % (st["kernel_ms_avg"] * 1e3), "launches", st["launches"],
           "work_launches", t[15], "accepted/launch %.1f" % (t[12] / max(1, t[15])),
           "avg stages_us: main+ticket %.2f reduce %.2f posterior %.2f walk %.2f" % tuple(t[8 + i] / 100.0 / max(1, t[15]) for i in range(4)),
+          "| last arriver: skew %.2f loop %.2f reduce+drain %.2f ticket %.2f" % tuple(t[i] / 100.0 / max(1, t[15]) for i in (17, 13, 14, 16)),
           "sweep_ms %.1f" % st["device_ms"])
