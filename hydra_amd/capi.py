@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libhgibbs.so")
 # every symbol include/hgibbs.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "hgibbs_last_error", "hgibbs_version", "hgibbs_create", "hgibbs_destroy", "hgibbs_comm_unique_id",
-    "hgibbs_comm_init", "hgibbs_load_bed", "hgibbs_synth_bed", "hgibbs_dims", "hgibbs_get_bed",
+    "hgibbs_comm_init", "hgibbs_comm_init_external", "hgibbs_p2p_export", "hgibbs_p2p_import", "hgibbs_load_bed", "hgibbs_synth_bed", "hgibbs_dims", "hgibbs_get_bed",
     "hgibbs_marker_stats", "hgibbs_set_residual", "hgibbs_get_residual", "hgibbs_reduce_eps", "hgibbs_add_scalar",
     "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
     "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
@@ -35,6 +35,9 @@ class SweepStats(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("shuffle", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("groups", C.POINTER(C.c_int32)), ("mS", C.POINTER(C.c_double))]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 
 class HgError(RuntimeError):
@@ -59,6 +62,9 @@ def lib():
     L.hgibbs_destroy.argtypes = [vp]
     L.hgibbs_comm_unique_id.argtypes = [C.c_void_p]
     L.hgibbs_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.hgibbs_comm_init_external.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    L.hgibbs_p2p_export.argtypes = [vp, C.c_void_p]
+    L.hgibbs_p2p_import.argtypes = [vp, C.c_void_p]
     L.hgibbs_load_bed.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.hgibbs_synth_bed.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double]
     L.hgibbs_dims.argtypes = [vp, u32p, u32p, u32p, u32p]
@@ -142,6 +148,31 @@ class Device:
     def comm_init(self, nranks, rank, uid):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid) if uid else None
         check(self.L.hgibbs_comm_init(self.h, nranks, rank, buf))
+
+    def comm_init_external(self, nranks, rank, allreduce):
+        """allreduce(numpy_array) must sum the array in place over all ranks."""
+        def cb(user, buf, count, dtype):
+            try:
+                ty = C.c_double if dtype == 0 else C.c_uint64
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ty)), shape=(count,))
+                allreduce(arr)
+                return 0
+            except Exception:  # pragma: no cover - reported through the return code
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLREDUCE_FN(cb)  # keep alive
+        check(self.L.hgibbs_comm_init_external(self.h, nranks, rank, self._cb, None))
+
+    def p2p_export(self):
+        buf = (C.c_uint8 * 64)()
+        check(self.L.hgibbs_p2p_export(self.h, buf))
+        return bytes(buf)
+
+    def p2p_import(self, handles):
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        check(self.L.hgibbs_p2p_import(self.h, buf))
 
     # -- data --
     def _dims(self):

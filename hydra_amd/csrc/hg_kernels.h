@@ -53,6 +53,7 @@ constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
 constexpr int ROWS_CAP = NSUM * MAX_BATCH + 8; // partial rows per slice (padded)
+constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
 struct SweepDesc {
@@ -66,6 +67,16 @@ struct SweepDesc {
     uint64_t nnz;          // markers with deltaBeta != 0 so far
     uint64_t launches;     // launches that did work
     uint64_t accepted_sum; // total accepted markers (== cursor at the end)
+    uint64_t seq;          // batches since the handle was created (epoch of the cross-GPU exchange)
+};
+
+// In-launch cross-GPU exchange (xGMI peer mailboxes, IPC-mapped).  Rank r's
+// mailbox holds, per parity, one row block and one flag word per source rank.
+struct P2PParams {
+    int nranks;                              // 0/1 = disabled
+    int rank;
+    double* data[MAX_RANKS];                 // data[r]  = base of rank r's mailbox rows [2][MAX_RANKS][ROWS_CAP]
+    unsigned long long* flags[MAX_RANKS];    // flags[r] = base of rank r's flags      [2][MAX_RANKS]
 };
 
 struct SweepParams {
@@ -114,6 +125,7 @@ struct SweepParams {
     // leaves sums[NSUM*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;
     unsigned long long* dbg; // optional stage timestamps (wall_clock64, 100 MHz)
+    P2PParams p2p;
 };
 
 // ---------------------------------------------------------------------------

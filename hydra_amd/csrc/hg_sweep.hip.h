@@ -297,6 +297,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             sh.flags[1] = pos;
             n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
             n.launches = d.launches + 1;
+            n.seq = d.seq + 1;
             n.accepted_sum = d.accepted_sum + naccept;
             if (f_err) n.error = f_err;
             *p.desc = n;
@@ -319,6 +320,57 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hg_smem[];
+
+#define HG_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+// Cross-GPU sum of the batch rows held in sh.tot, inside the launch: push my
+// rows into every rank's mailbox (system-scope stores over xGMI), publish one
+// flag per destination, wait for the nranks flags in my own mailbox, then add
+// the contributions in RANK ORDER so that every GPU gets the same bits.  Two
+// parities: a peer can be at most one batch ahead (it needs my rows of batch
+// b+1 before it can finish b+1).  Bounded spin: returns false on timeout.
+__device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh)
+{
+    const int tid = threadIdx.x;
+    const int nr = p.p2p.nranks, me = p.p2p.rank;
+    const uint32_t nrows = NSUM * nb + 1;
+    const uint32_t parity = (uint32_t)(d.seq & 1ull);
+    const unsigned long long epoch = d.seq + 1ull;
+    const size_t slot = (size_t)(parity * MAX_RANKS + (uint32_t)me) * ROWS_CAP;
+    for (uint32_t it = tid; it < nrows * (uint32_t)nr; it += BLOCK) {
+        const uint32_t dst = it / nrows, rr = it % nrows;
+        const double v = sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr];
+        __hip_atomic_store(p.p2p.data[dst] + slot + rr, v, HG_RLX_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < nr) __hip_atomic_store(p.p2p.flags[tid] + parity * MAX_RANKS + me, epoch, HG_RLX_SYSTEM);
+    bool ok = true;
+    if (tid < nr) {
+        const unsigned long long* f = p.p2p.flags[me] + parity * MAX_RANKS + tid;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, HG_RLX_SYSTEM) != epoch) {
+            if (wall_clock64() - t0 > 300000000ull) { // 3 s at 100 MHz: a peer is gone
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (!ok) sh.flags[2] = 1u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    if (sh.flags[2]) return false;
+    for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
+        double acc = 0.0;
+        for (int r = 0; r < nr; ++r)
+            acc += __hip_atomic_load(p.p2p.data[me] + (size_t)(parity * MAX_RANKS + (uint32_t)r) * ROWS_CAP + rr, HG_RLX_SYSTEM);
+        sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr] = acc;
+    }
+    __syncthreads();
+    return true;
+}
 
 // One launch of the sweep.  grid = (S, ceil(batch/cols_per_group)): blockIdx.y
 // owns a group of up to CPG batch columns, blockIdx.x a strided set of tile
@@ -479,6 +531,18 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     __syncthreads();
     if (p.dbg && tid == 0) p.dbg[2] = wall_clock64();
 
+    if (p.p2p.nranks > 1 && !p.sums_out) { // multi-GPU, in-launch exchange
+        if (tid == 0) sh.flags[2] = 0u;
+        __syncthreads();
+        if (!p2p_exchange(p, d, nb, sh)) {
+            if (tid == 0) {
+                SweepDesc n = d;
+                n.error = 3u;
+                *p.desc = n;
+            }
+            return;
+        }
+    }
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
         for (int r = tid; r < NSUM * MAX_BATCH + 1; r += BLOCK) {
             double v = 0.0;

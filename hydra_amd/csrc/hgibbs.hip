@@ -59,6 +59,13 @@ struct hgibbs_ctx {
     // sharding
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    hgibbs_allreduce_fn ext_fn = nullptr; // bulk reductions through the caller's transport
+    void* ext_user = nullptr;
+    // in-launch exchange: own mailbox + IPC-mapped peers
+    unsigned char* mbox = nullptr;
+    void* peer_base[MAX_RANKS] = {};
+    bool p2p_ready = false, p2p_enabled = true;
+    uint64_t batch_seq = 0;
 
     // data
     uint32_t n_global = 0, n_local = 0, n_pad = 0, M = 0, row_begin = 0;
@@ -116,6 +123,28 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
     if (h->scratch) HIP_TRY(hipFree(h->scratch));
     HIP_TRY(hipMalloc(&h->scratch, n * sizeof(double)));
     h->scratch_n = n;
+    return 0;
+}
+
+static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
+static constexpr size_t MBOX_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long);
+
+// Sum a device buffer over ranks (rare, bulk): RCCL when a communicator exists,
+// else the caller's transport on a host copy.  dtype 0 = f64, 1 = u64.
+static int bulk_allreduce(hgibbs_ctx* h, void* dptr, size_t count, int dtype)
+{
+    if (h->nranks <= 1 && !h->comm) return 0;
+    if (h->comm) {
+        NCCL_TRY(ncclAllReduce(dptr, dptr, count, dtype == 0 ? ncclDouble : ncclUint64, ncclSum, h->comm, h->stream));
+        return 0;
+    }
+    if (!h->ext_fn) return fail("multi-rank handle without a transport: call hgibbs_comm_init or hgibbs_comm_init_external");
+    std::vector<unsigned char> buf(count * 8);
+    HIP_TRY(hipMemcpyAsync(buf.data(), dptr, buf.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->ext_fn(h->ext_user, buf.data(), count, dtype)) return fail("external all-reduce callback failed");
+    HIP_TRY(hipMemcpyAsync(dptr, buf.data(), buf.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -446,6 +475,9 @@ int hgibbs_destroy(hgibbs_t h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
+    for (int r = 0; r < MAX_RANKS; ++r)
+        if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
+    if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
                     h->adaV, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
     for (void* p : ptrs)
@@ -480,6 +512,64 @@ int hgibbs_comm_init(hgibbs_t h, int nranks, int rank, const void* id128)
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     NCCL_TRY(ncclCommInitRank(&h->comm, nranks, id, rank));
+    return 0;
+}
+
+extern "C" int hgibbs_comm_init_external(hgibbs_t h, int nranks, int rank, hgibbs_allreduce_fn fn, void* user)
+{
+    if (!h) return fail("null handle");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("hgibbs_comm_init_external: bad rank %d of %d", rank, nranks);
+    if (nranks > 1 && !fn) return fail("hgibbs_comm_init_external: null callback");
+    h->nranks = nranks;
+    h->rank = rank;
+    h->ext_fn = fn;
+    h->ext_user = user;
+    return 0;
+}
+
+extern "C" int hgibbs_p2p_export(hgibbs_t h, void* handle64)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!h || !handle64) return fail("hgibbs_p2p_export: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->mbox) {
+        // uncached (fine-grained) device memory: remote GPUs' stores must be visible to local loads
+        void* p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, MBOX_BYTES, hipDeviceMallocUncached);
+        hipIpcMemHandle_t probe;
+        if (e != hipSuccess || hipIpcGetMemHandle(&probe, p) != hipSuccess) {
+            (void)hipGetLastError();
+            if (e == hipSuccess) (void)hipFree(p);
+            HIP_TRY(hipMalloc(&p, MBOX_BYTES));
+        }
+        h->mbox = (unsigned char*)p;
+        HIP_TRY(hipMemset(h->mbox, 0, MBOX_BYTES));
+    }
+    hipIpcMemHandle_t hd;
+    HIP_TRY(hipIpcGetMemHandle(&hd, h->mbox));
+    std::memcpy(handle64, &hd, sizeof hd);
+    return 0;
+}
+
+extern "C" int hgibbs_p2p_import(hgibbs_t h, const void* handles)
+{
+    if (!h || !handles) return fail("hgibbs_p2p_import: null argument");
+    if (h->nranks < 2) return fail("hgibbs_p2p_import: initialise the ranks first (hgibbs_comm_init / hgibbs_comm_init_external)");
+    if (h->nranks > MAX_RANKS) return fail("hgibbs_p2p_import: at most %d ranks", MAX_RANKS);
+    if (!h->mbox) return fail("hgibbs_p2p_import: call hgibbs_p2p_export first");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int r = 0; r < h->nranks; ++r) {
+        if (r == h->rank) {
+            h->peer_base[r] = h->mbox;
+            continue;
+        }
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, (const unsigned char*)handles + (size_t)r * 64, sizeof hd);
+        void* p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+        h->peer_base[r] = p;
+    }
+    h->p2p_ready = true;
     return 0;
 }
 
@@ -620,7 +710,7 @@ static int compute_stats(hgibbs_ctx* h)
     if (h->have_stats) return 0;
     k_counts<<<h->M, BLOCK, 0, h->stream>>>(h->bed, h->stride, h->n_pad, h->n_local, h->counts, h->M);
     HIP_TRY(hipGetLastError());
-    if (h->comm) NCCL_TRY(ncclAllReduce(h->counts, h->counts, (size_t)h->M * 3, ncclUint64, ncclSum, h->comm, h->stream));
+    if (bulk_allreduce(h, h->counts, (size_t)h->M * 3, 1)) return 1;
     k_stats<<<(h->M + 255) / 256, 256, 0, h->stream>>>(h->counts, h->n_global, h->mave, h->mstd, h->M);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -683,7 +773,7 @@ int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
     k_reduce_eps<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], h->n_pad, h->scratch);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 2, h->sums);
     HIP_TRY(hipGetLastError());
-    if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 2, ncclDouble, ncclSum, h->comm, h->stream));
+    if (bulk_allreduce(h, h->sums, 2, 0)) return 1;
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (sum) *sum = h->scratch_host[0];
@@ -728,7 +818,7 @@ int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num)
     k_dot_one<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, marker, h->eps[h->eps_cur], h->scratch);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 4, h->sums);
     HIP_TRY(hipGetLastError());
-    if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, 4, ncclDouble, ncclSum, h->comm, h->stream));
+    if (bulk_allreduce(h, h->sums, 4, 0)) return 1;
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host + 4, h->mave + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(h->scratch_host + 5, h->mstd + marker, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -815,6 +905,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "p2p")) {
+        h->p2p_enabled = value != 0;
     } else if (!std::strcmp(name, "force_split")) {
         h->force_split = value != 0;
     } else if (!std::strcmp(name, "debug_timing")) {
@@ -897,6 +989,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     d0.cur = h->eps_cur;
     d0.batch = h->batch;
     d0.rng_idx = rng->idx;
+    d0.seq = h->batch_seq;
     *h->desc_host = d0;
     HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream)); // staging buffers are on the host stack / pageable
@@ -939,8 +1032,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
-    const bool split = h->nranks > 1 || h->force_split;
+    const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
+    const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
+    if (h->nranks > 1 && split && !h->comm)
+        return fail("hgibbs_sweep: %d ranks but no per-batch transport (hgibbs_comm_init for RCCL or hgibbs_p2p_import)", h->nranks);
     p.sums_out = split ? h->sums : nullptr;
+    p.p2p.nranks = use_p2p ? h->nranks : 0;
+    p.p2p.rank = h->rank;
+    for (int r = 0; r < MAX_RANKS; ++r) {
+        p.p2p.data[r] = (use_p2p && r < h->nranks) ? (double*)h->peer_base[r] : nullptr;
+        p.p2p.flags[r] = (use_p2p && r < h->nranks) ? (unsigned long long*)((unsigned char*)h->peer_base[r] + MBOX_DATA_BYTES) : nullptr;
+    }
 
     const uint32_t ntg = h->n_pad / BLOCK_IND;
     const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
@@ -968,7 +1070,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->desc_host, h->desc, sizeof(SweepDesc), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun)", dh.error, dh.cursor);
+        if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out)", dh.error, dh.cursor);
         if (dh.launches > 0) avg_accept = std::max(1.0, (double)dh.accepted_sum / (double)dh.launches);
         if (dh.cursor >= M && dh.pend_marker < 0) break;
     }
@@ -978,6 +1080,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
 
     h->eps_cur = h->desc_host->cur;
+    h->batch_seq = h->desc_host->seq;
     rng->idx = h->desc_host->rng_idx;
     HIP_TRY(hipMemcpy(rng->x, h->mt, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (cass_host) HIP_TRY(hipMemcpy(cass_host, h->cass, (size_t)G * K * sizeof(int32_t), hipMemcpyDeviceToHost));

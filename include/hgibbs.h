@@ -55,6 +55,19 @@ int hgibbs_destroy(hgibbs_t h);
  * hgibbs_comm_init.  nranks == 1 needs neither call. */
 int hgibbs_comm_unique_id(void* id128);
 int hgibbs_comm_init(hgibbs_t h, int nranks, int rank, const void* id128);
+/* Alternative to RCCL for the rare bulk reductions (load-time counts, per
+ * iteration sums): the caller reduces a HOST buffer over its own transport
+ * (MPI_Allreduce, gloo ...).  dtype 0 = f64, 1 = u64; returns 0 on success. */
+typedef int (*hgibbs_allreduce_fn)(void* user, void* buf_host, size_t count, int dtype);
+int hgibbs_comm_init_external(hgibbs_t h, int nranks, int rank, hgibbs_allreduce_fn fn, void* user);
+/* In-launch exchange of the per-batch scalars over xGMI: every rank exports a
+ * 64-byte IPC handle of its mailbox, the caller gathers the nranks handles
+ * (rank order) and every rank imports them.  When imported, hgibbs_sweep sums
+ * the ranks' (s1,s2) rows inside the sweep kernel -- each GPU pushes its rows
+ * into all peers' mailboxes and adds the nranks contributions in rank order --
+ * instead of splitting every batch around an ncclAllReduce launch. */
+int hgibbs_p2p_export(hgibbs_t h, void* handle64);
+int hgibbs_p2p_import(hgibbs_t h, const void* handles /* nranks * 64 bytes */);
 
 /* ---- data: replaces Data::load_data_from_bed_file + sparse index build
  * (src/data.cpp:671-739, :1224-1290) -------------------------------------- */

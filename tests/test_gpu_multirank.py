@@ -1,0 +1,103 @@
+"""Multi-rank paths on ONE GPU: two processes share device 0, individuals are
+sharded between them, bulk reductions go through gloo (hgibbs_comm_init_external)
+and the per-batch (s1,s2) rows through the in-launch peer-mailbox exchange
+(hgibbs_p2p_export/import; IPC-mapped memory, the same code path that runs over
+xGMI between GPUs).  Result must equal the single-rank chain: components exact,
+beta to 1e-9; both replicas bit-identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(N, world, rank):
+    per = ((N + world - 1) // world + 3) // 4 * 4
+    return min(N, rank * per), min(N, (rank + 1) * per)
+
+
+def _worker(rank, world, port, bed, y, N, iters, batch, q):
+    import torch
+    import torch.distributed as dist
+    from hydra_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = capi.Device(0)
+
+        def allreduce(arr):
+            if arr.dtype == np.uint64:
+                t = torch.from_numpy(arr.view(np.int64))
+            else:
+                t = torch.from_numpy(arr)
+            dist.all_reduce(t)
+
+        dev.comm_init_external(world, rank, allreduce)
+        handles = [None] * world
+        dist.all_gather_object(handles, dev.p2p_export())
+        dev.p2p_import(handles)
+        lo, hi = _shard(N, world, rank)
+        dev.load_bed(bed, N, row_begin=lo, row_end=hi, n_global=N)
+        dev.set_option("batch", batch)
+        ch = capi.Chain(dev, y, seed=1222)
+        for _ in range(iters):
+            ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st = ch.state()
+        q.put((rank, beta, comp, st["sigmaE"], st["sigmaG"], dev.get_residual(), ch.last_nnz()))
+    except Exception as e:  # surface the error text in the parent
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [16, 64])
+def test_two_ranks_one_gpu_p2p_exchange(batch):
+    import torch.multiprocessing as mp
+    from hydra_amd import capi, synth
+    M, N, iters = 300, 9000, 3
+    geno = synth.make_genotypes(M, N, seed=61, missing_rate=0.01)
+    y, _ = synth.make_phenotype(geno, seed=62, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bed, y, N, iters, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert len(r) == 7, "rank %s failed: %s" % (r[0], r[1])
+    res.sort(key=lambda r: r[0])
+
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_option("batch", batch)
+    ch = capi.Chain(dev, y, seed=1222)
+    for _ in range(iters):
+        ch.iterate()
+    beta, comp, _ = dev.get_beta()
+    st = ch.state()
+    # replicas identical
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+    # equal to the single-rank chain (different summation tree: tolerance on beta, exact components)
+    assert np.array_equal(res[0][2], comp)
+    assert np.all(np.abs(res[0][1] - beta) <= 1e-9 * np.maximum(1.0, np.abs(beta)))
+    assert abs(res[0][3] - st["sigmaE"]) <= 1e-9 * st["sigmaE"]
+    eps = np.concatenate([res[0][5], res[1][5]])
+    assert np.allclose(eps, dev.get_residual(), rtol=0, atol=1e-9)
+    assert res[0][6] == ch.last_nnz()
