@@ -75,6 +75,87 @@ def make_phenotype_on_device(dev, n_global, M, rank_rows, seed, h2=0.5, causal_f
     return dev.get_residual()
 
 
+def make_multirank_device(capi, dist, world, rank, local_rank, want_p2p):
+    """One handle per rank: a communicator for the rare bulk reductions (RCCL; or
+    gloo through the external hook when HGIBBS_BENCH_BULK=gloo, which is how two
+    ranks can share one GPU in rehearsals) and, if asked for and available on
+    every rank, the in-launch peer-mailbox exchange for the per-batch scalars.
+    Every collective below is executed by every rank whatever fails locally.
+    Returns (device, p2p_enabled)."""
+    import torch
+    dev = capi.Device(local_rank)
+    if os.environ.get("HGIBBS_BENCH_BULK", "rccl") == "gloo":
+        def allreduce(arr):
+            t = torch.from_numpy(arr.view(np.int64) if arr.dtype == np.uint64 else arr)
+            dist.all_reduce(t)
+        dev.comm_init_external(world, rank, allreduce)
+    else:
+        uid = [capi.Device.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dev.comm_init(world, rank, uid[0])
+    handle = None
+    if want_p2p:
+        try:
+            handle = dev.p2p_export()
+        except Exception as e:
+            print("rank %d: p2p export failed: %r" % (rank, e), file=sys.stderr)
+    handles = [None] * world
+    dist.all_gather_object(handles, handle)
+    ok = 0
+    if want_p2p and all(h is not None for h in handles):
+        try:
+            dev.p2p_import(handles)
+            ok = 1
+        except Exception as e:
+            print("rank %d: p2p import failed: %r" % (rank, e), file=sys.stderr)
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    p2p = bool(int(t[0]))
+    dev.set_option("p2p", 1 if p2p else 0)
+    return dev, p2p
+
+
+def exchange_self_check(capi, dist, world, rank, local_rank):
+    """Run the same tiny sharded chain once with the peer-mailbox exchange and
+    once with the RCCL split path; the former is used for the timed run only if
+    it reproduces the latter (components exact, beta to 1e-9) on every rank."""
+    import torch
+    Ns, Ms = 16384, 1500
+    per = ((Ns + world - 1) // world + 3) // 4 * 4
+    lo, hi = min(Ns, rank * per), min(Ns, (rank + 1) * per)
+    y = np.random.default_rng(7).normal(size=Ns)
+    out = []
+    variants = (True,) if os.environ.get("HGIBBS_BENCH_BULK", "rccl") == "gloo" else (True, False)
+    for want_p2p in variants:
+        ok = 1
+        res = None
+        try:
+            d, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
+            if want_p2p and not p2p:
+                raise RuntimeError("p2p import failed on some rank")
+            d.set_option("batch", 64)
+            d.synth_bed(Ns, Ms, seed=5, row_begin=lo, row_end=hi)
+            ch = capi.Chain(d, y, seed=99)
+            for _ in range(2):
+                ch.iterate()
+            res = d.get_beta()[:2]
+            d.close()
+        except Exception as e:
+            print("rank %d: exchange self-check (%s) failed: %r" % (rank, "p2p" if want_p2p else "rccl", e), file=sys.stderr)
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        out.append(res if int(t[0]) else None)
+    if len(out) == 1:
+        return out[0] is not None
+    if out[0] is None or out[1] is None:
+        return out[0] is not None and out[1] is None  # p2p only if it is the one that works
+    same = np.array_equal(out[0][1], out[1][1]) and np.all(np.abs(out[0][0] - out[1][0]) <= 1e-9 * np.maximum(1.0, np.abs(out[1][0])))
+    t = torch.tensor([1 if same else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t[0]))
+
+
 def cpu_baseline(dev, y_local_is_full, y, N, M, mS, groups, sample_markers, threads):
     """The oracle (CPU restatement of hydra's path, OpenMP over individuals as
     the reference's loops are) timed on a bounded sample: the first
@@ -114,13 +195,15 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="speculative batch width (0 = library default)")
     ap.add_argument("--cpg", type=int, default=0, help="columns per workgroup column-group")
     ap.add_argument("--missing", type=float, default=0.0)
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="per-batch cross-GPU exchange: in-launch peer mailboxes, RCCL all-reduce, or self-checked choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="markers in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("HGIBBS_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
@@ -146,11 +229,17 @@ def main():
     per = ((N + world - 1) // world + 3) // 4 * 4
     lo, hi = min(N, rank * per), min(N, (rank + 1) * per)
 
-    dev = capi.Device(local_rank)
+    exchange = "none"
     if world > 1:
-        uid = [capi.Device.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        dev.comm_init(world, rank, uid[0])
+        want_p2p = args.exchange in ("auto", "p2p") and os.environ.get("HGIBBS_DISABLE_P2P", "0") != "1"
+        if want_p2p and args.exchange == "auto":
+            want_p2p = exchange_self_check(capi, dist, world, rank, local_rank)
+        dev, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
+        exchange = "p2p-mailbox" if p2p else "rccl-allreduce"
+        if not args.batch:
+            dev.set_option("batch", 128)  # per-batch exchange costs more than a launch: wider batches
+    else:
+        dev = capi.Device(local_rank)
     if args.batch:
         dev.set_option("batch", args.batch)
     if args.cpg:
@@ -216,7 +305,7 @@ def main():
             "config": {"workload": "BayesRR %s: N=%d individuals x M=%d markers, K=%d mixture, G=%d groups, "
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
-                       "N": N, "M": M, "batch": args.batch or 64, "nnz_updates_per_iter": nnz / K,
+                       "N": N, "M": M, "batch": args.batch or (64 if world == 1 else 128), "exchange": exchange, "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": launches / K, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or 64, world),

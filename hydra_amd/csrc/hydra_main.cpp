@@ -326,12 +326,62 @@ int main(int argc, const char* argv[])
             std::fclose(f);
         }
         hg_check(hgibbs_comm_init(dev, nranks, rank, id), "hgibbs_comm_init");
+        // in-launch peer-mailbox exchange: every rank publishes its IPC handle next to the id file
+        uint8_t mine[64];
+        std::vector<uint8_t> all((size_t)nranks * 64);
+        bool p2p_ok = hgibbs_p2p_export(dev, mine) == 0;
+        {
+            const std::string hf = base + ".p2p." + std::to_string(rank);
+            FILE* f = std::fopen((hf + ".tmp").c_str(), "wb");
+            if (f) {
+                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
+                std::fwrite(mine, 1, 64, f);
+                std::fclose(f);
+                std::rename((hf + ".tmp").c_str(), hf.c_str());
+            }
+        }
+        for (int r = 0; r < nranks; ++r) {
+            const std::string hf = base + ".p2p." + std::to_string(r);
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = std::fopen(hf.c_str(), "rb")); ++tries)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            char flag = 'N';
+            if (!f || std::fread(&flag, 1, 1, f) != 1 || std::fread(all.data() + (size_t)r * 64, 1, 64, f) != 64 || flag != 'Y') p2p_ok = false;
+            if (f) std::fclose(f);
+        }
+        if (p2p_ok && hgibbs_p2p_import(dev, all.data()) != 0) p2p_ok = false;
+        // a rank that could not import falls back to RCCL; all ranks must agree, so publish the verdict too
+        {
+            const std::string vf = base + ".p2pok." + std::to_string(rank);
+            FILE* f = std::fopen((vf + ".tmp").c_str(), "wb");
+            if (f) {
+                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
+                std::fclose(f);
+                std::rename((vf + ".tmp").c_str(), vf.c_str());
+            }
+            for (int r = 0; r < nranks; ++r) {
+                const std::string of = base + ".p2pok." + std::to_string(r);
+                FILE* g = nullptr;
+                for (int tries = 0; tries < 6000 && !(g = std::fopen(of.c_str(), "rb")); ++tries)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                char flag = 'N';
+                if (!g || std::fread(&flag, 1, 1, g) != 1 || flag != 'Y') p2p_ok = false;
+                if (g) std::fclose(g);
+            }
+        }
+        hg_check(hgibbs_set_option(dev, "p2p", p2p_ok ? 1 : 0), "p2p");
+        if (rank == 0) std::printf("INFO   : per-batch exchange over %s\n", p2p_ok ? "xGMI peer mailboxes (in-launch)" : "RCCL all-reduce");
         if (rank == 0) {
-            std::this_thread::sleep_for(std::chrono::milliseconds(200));
+            std::this_thread::sleep_for(std::chrono::milliseconds(500));
             std::remove(idf.c_str());
+            for (int r = 0; r < nranks; ++r) {
+                std::remove((base + ".p2p." + std::to_string(r)).c_str());
+                std::remove((base + ".p2pok." + std::to_string(r)).c_str());
+            }
         }
     }
     if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
+    else if (nranks > 1) hg_check(hgibbs_set_option(dev, "batch", 128), "batch");
     if (opt.cpg) hg_check(hgibbs_set_option(dev, "cols_per_group", opt.cpg), "cols_per_group");
 
     // ---- genotypes: Data::load_data_from_bed_file, data.cpp:671-739 -----------
