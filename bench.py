@@ -236,8 +236,6 @@ def main():
             want_p2p = exchange_self_check(capi, dist, world, rank, local_rank)
         dev, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
         exchange = "p2p-mailbox" if p2p else "rccl-allreduce"
-        if not args.batch:
-            dev.set_option("batch", 128)  # per-batch exchange costs more than a launch: wider batches
     else:
         dev = capi.Device(local_rank)
     if args.batch:
@@ -305,10 +303,10 @@ def main():
             "config": {"workload": "BayesRR %s: N=%d individuals x M=%d markers, K=%d mixture, G=%d groups, "
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
-                       "N": N, "M": M, "batch": args.batch or (64 if world == 1 else 128), "exchange": exchange, "nnz_updates_per_iter": nnz / K,
+                       "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": launches / K, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or 64, world),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (128 if (hi - lo) >= 200000 or world > 1 else 64), world),
                          "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
                          "sweep_ms_per_iter": sweep_ms / K},

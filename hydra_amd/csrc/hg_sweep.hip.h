@@ -1,6 +1,8 @@
 // hg_sweep.hip.h -- the hot kernel (see hg_kernels.h for the design summary).
 #pragma once
 
+#include <utility>
+
 #include "hg_kernels.h"
 
 namespace hg {
@@ -169,10 +171,22 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             double num = dp;
             num += mm.bold * p.n_minus_1;
 
-            const bool staged = p.GK <= HT_LDS;
-            const double* den = (staged ? sh.htab : p.denom) + (size_t)mm.grp * K;
-            const double* lpi = (staged ? sh.htab + HT_LDS : p.logpi) + (size_t)mm.grp * K;
-            const double* hlg = (staged ? sh.htab + 2 * HT_LDS : p.hlog) + (size_t)mm.grp * K;
+            // group's table rows into registers through typed (LDS or global) pointers: a
+            // pointer select would make every access a flat load with a full wait
+            double den[MAX_K], lpi[MAX_K], hlg[MAX_K];
+            if (p.GK <= HT_LDS) {
+                for (int k = 0; k < K; ++k) {
+                    den[k] = sh.htab[mm.grp * K + k];
+                    lpi[k] = sh.htab[HT_LDS + mm.grp * K + k];
+                    hlg[k] = sh.htab[2 * HT_LDS + mm.grp * K + k];
+                }
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    den[k] = p.denom[(size_t)mm.grp * K + k];
+                    lpi[k] = p.logpi[(size_t)mm.grp * K + k];
+                    hlg[k] = p.hlog[(size_t)mm.grp * K + k];
+                }
+            }
             sh.logl[tid * K] = lpi[0];
             sh.muk[tid * K] = 0.0;
             for (int k = 1; k < K; ++k) {
@@ -248,7 +262,8 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             if ((uint32_t)lane == f && ada && k > 0) {
                 LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
                 ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
-                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], (p.GK <= HT_LDS ? sh.htab + 3 * HT_LDS : p.sdk)[(size_t)grp * K + k]);
+                const double sd = (p.GK <= HT_LDS) ? sh.htab[3 * HT_LDS + grp * K + k] : p.sdk[(size_t)grp * K + k];
+                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], sd);
                 consumed = g.pos - (pos + jeff + 1u);
                 gerr = g.err;
             }
@@ -322,6 +337,41 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
 extern __shared__ __attribute__((aligned(16))) unsigned char hg_smem[];
 
 #define HG_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+// Inner step of the dot product for one slot S of four columns: field extract,
+// int -> f64, fused multiply-add, issued as three groups of four so that the
+// in-order SIMD always has three independent instructions between a producer and
+// its consumer (hipcc serialises the plain C++ form through one temporary).
+// a += double((g >> 2S) & 3) * e  -- the product is exact, one rounding per add.
+template <int S>
+__device__ __forceinline__ void fma_slot4(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, double e, double& a0, double& a1,
+                                          double& a2, double& a3)
+{
+    uint32_t t0, t1, t2, t3;
+    double w0, w1, w2, w3;
+    asm("v_bfe_u32 %[t0], %[g0], %[sh], 2\n\t"
+        "v_bfe_u32 %[t1], %[g1], %[sh], 2\n\t"
+        "v_bfe_u32 %[t2], %[g2], %[sh], 2\n\t"
+        "v_bfe_u32 %[t3], %[g3], %[sh], 2\n\t"
+        "v_cvt_f64_u32 %[w0], %[t0]\n\t"
+        "v_cvt_f64_u32 %[w1], %[t1]\n\t"
+        "v_cvt_f64_u32 %[w2], %[t2]\n\t"
+        "v_cvt_f64_u32 %[w3], %[t3]\n\t"
+        "v_fmac_f64 %[a0], %[w0], %[e]\n\t"
+        "v_fmac_f64 %[a1], %[w1], %[e]\n\t"
+        "v_fmac_f64 %[a2], %[w2], %[e]\n\t"
+        "v_fmac_f64 %[a3], %[w3], %[e]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [t3] "=&v"(t3), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)
+        : [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [e] "v"(e), [sh] "i"(2 * S));
+}
+
+template <int... S>
+__device__ __forceinline__ void fma_slots4(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, const double (&e)[IPT], double& a0,
+                                           double& a1, double& a2, double& a3, std::integer_sequence<int, S...>)
+{
+    (fma_slot4<S>(g0, g1, g2, g3, e[S], a0, a1, a2, a3), ...);
+}
 
 // Cross-GPU sum of the batch rows held in sh.tot, inside the launch: push my
 // rows into every rank's mailbox (system-scope stores over xGMI), publish one
@@ -435,16 +485,29 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
 #pragma unroll
                 for (int i = 0; i < IPT; ++i) sall += e[i];
             }
+            uint32_t gw[CPG], nm[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) code_weights(w[c], gw[c], nm[c]);
+            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add.  Slot-major order
+            // so that consecutive instructions feed CPG independent accumulator chains
+            // (each column still adds its slots in increasing order).
+            if constexpr (CPG % 4 == 0) {
+#pragma unroll
+                for (int c0g = 0; c0g < CPG; c0g += 4)
+                    fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
+                               std::make_integer_sequence<int, IPT>{});
+            } else {
+#pragma unroll
+                for (int s = 0; s < IPT; ++s) {
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) a1[c] = __builtin_fma((double)((gw[c] >> (2 * s)) & 3u), e[s], a1[c]);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < CPG; ++c) {
-                uint32_t gw, nm;
-                code_weights(w[c], gw, nm);
-#pragma unroll
-                for (int s = 0; s < IPT; ++s) // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add
-                    a1[c] = __builtin_fma((double)((gw >> (2 * s)) & 3u), e[s], a1[c]);
                 if (cmiss[c]) {
 #pragma unroll
-                    for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm >> (2 * s)) & 1u), e[s], a2[c]);
+                    for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
                 }
             }
         }

@@ -108,7 +108,7 @@ struct hgibbs_ctx {
     double* beta_host = nullptr;    // pinned, M doubles (lazy)
 
     // options
-    uint32_t batch = 64;
+    uint32_t batch = 0; // 0 = auto: 128 for shards of >= 200k individuals, else 64
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
@@ -897,7 +897,7 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
 {
     if (!h || !name) return fail("hgibbs_set_option: null argument");
     if (!std::strcmp(name, "batch")) {
-        if (value < 1 || value > MAX_BATCH) return fail("batch must be in [1,%d]", MAX_BATCH);
+        if (value < 0 || value > MAX_BATCH) return fail("batch must be in [0,%d] (0 = auto)", MAX_BATCH);
         h->batch = (uint32_t)value;
     } else if (!std::strcmp(name, "cols_per_group")) {
         if (value != 2 && value != 4 && value != 8 && value != 16) return fail("cols_per_group must be 2, 4, 8 or 16");
@@ -982,12 +982,13 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipGetLastError());
 
     const uint32_t cpg = h->cols_per_group;
-    const uint32_t ngroups = (h->batch + cpg - 1) / cpg;
+    const uint32_t batch = h->batch ? h->batch : ((h->n_local >= 200000u || h->nranks > 1) ? 128u : 64u);
+    const uint32_t ngroups = (batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
     d0.pend_marker = -1;
     d0.cur = h->eps_cur;
-    d0.batch = h->batch;
+    d0.batch = batch;
     d0.rng_idx = rng->idx;
     d0.seq = h->batch_seq;
     *h->desc_host = d0;
@@ -1045,11 +1046,12 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     }
 
     const uint32_t ntg = h->n_pad / BLOCK_IND;
-    const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
+    // auto: at most 768 workgroups (3 per CU at the kernel's register budget) so the grid is co-resident
+    const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : std::min<uint32_t>(S_CAP, std::max<uint32_t>(1u, 768u / ngroups)), ntg);
     const dim3 grid(S, ngroups);
     uint64_t total_launches = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    double avg_accept = std::max(1.0, (double)h->batch * 0.5);
+    double avg_accept = std::max(1.0, (double)batch * 0.5);
     for (;;) {
         const SweepDesc& dh = *h->desc_host;
         const uint32_t remaining = M - std::min(M, dh.cursor);

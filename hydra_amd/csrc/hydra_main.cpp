@@ -381,7 +381,6 @@ int main(int argc, const char* argv[])
         }
     }
     if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
-    else if (nranks > 1) hg_check(hgibbs_set_option(dev, "batch", 128), "batch");
     if (opt.cpg) hg_check(hgibbs_set_option(dev, "cols_per_group", opt.cpg), "cols_per_group");
 
     // ---- genotypes: Data::load_data_from_bed_file, data.cpp:671-739 -----------
