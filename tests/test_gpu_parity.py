@@ -461,3 +461,49 @@ def test_argument_errors_are_reported():
     with pytest.raises(capi.HgError):  # order outside [0, M)
         dev.sweep(np.array([0, 1, 2, 3, 4, 5, 6, 99], dtype=np.int32), st["sigmaE"], st["sigmaG"], st["estPi"],
                   np.ones(8, dtype=np.uint8), rng)
+
+
+REF_TOOLS = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_TOOLS, "pp_beta_converter")), reason="oracle/_ref tools not built")
+def test_reference_postproc_tools_read_our_files(oracle, tmp_path):
+    """the reference's own converters (postproc/*.cpp, compiled
+    unchanged into oracle/_ref) parse the CLI's output files and print the
+    oracle's numbers."""
+    M, N, iters = 40, 300, 4
+    geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=72, causal_frac=0.1)
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, synth.pack_bed_columns(geno), N, y=y)
+    r = subprocess.run([EXE, "--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--mcmc-out-dir", out,
+                        "--mcmc-out-name", "r", "--number-individuals", str(N), "--number-markers", str(M), "--chain-length",
+                        str(iters), "--thin", "1", "--save", "1", "--seed", "7", "--S", "0.001,0.01,0.1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = orc.Chain(oracle, synth.pack_bed_columns(geno), N, y, mS=np.array([[0.0, 0.001, 0.01, 0.1]]), seed=7)
+    betas = []
+    for _ in range(iters):
+        ref.iterate()
+        betas.append(ref.arr("beta").copy())
+    txt = subprocess.run([os.path.join(REF_TOOLS, "pp_beta_converter"), out + "/r.bet", str(iters - 1)], capture_output=True,
+                         text=True).stdout
+    assert "%d markers were processed." % M in txt
+    got = {}
+    for line in txt.splitlines():
+        if "/" in line and "=" in line and not line.startswith("read"):
+            left, val = line.split("=")
+            it, mk = left.split("/")
+            got[(int(it), int(mk))] = float(val)
+    assert len(got) == iters * M
+    for it in range(iters):
+        for mk in range(M):
+            assert abs(got[(it, mk)] - betas[it][mk]) < 1e-9
+    nz = subprocess.run([os.path.join(REF_TOOLS, "pp_extract_non_zero_betaAll"), out + "/r.bet", "0", str(iters - 1)],
+                        capture_output=True, text=True).stdout
+    rows = [l.split() for l in nz.splitlines() if l.strip()]
+    assert len(rows) == sum(int((np.abs(b) > 1e-17).sum()) for b in betas)
+    eps_txt = subprocess.run([os.path.join(REF_TOOLS, "pp_epsilon_converter"), out + "/r.eps.0"], capture_output=True, text=True).stdout
+    assert "iteration %d was last logged into epsilon file." % (iters - 1) in eps_txt and "%d individuals were processed." % N in eps_txt
+    vals = [float(l.split("=")[1]) for l in eps_txt.splitlines() if "/" in l and "=" in l]
+    assert np.allclose(vals, ref.arr("eps"), rtol=0, atol=1e-9)
