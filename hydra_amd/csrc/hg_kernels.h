@@ -121,6 +121,7 @@ struct SweepParams {
     uint32_t nblk_x;
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
+    uint32_t batch_limit;    // widest batch a launch may take (the batch option)
     // multi-GPU: when non-null the kernel stops after the local reduction and
     // leaves sums[NSUM*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;

@@ -41,7 +41,8 @@ struct SweepShared {
     double* mstd;
     int32_t* marker;
     int32_t* grp;
-    uint32_t* flags;   // [0] last-arriver flag, [1] stream position after the walk
+    uint32_t* flags;   // [0] last-arriver flag, [1] stream position after the walk, [2] exchange timeout, [3] accepted
+    uint32_t* red_u;   // 4 words: block minimum of the predicted-event scan
     uint8_t* ada;
     double* red;       // 128 doubles: exchange buffer of the tail reduction
     double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
@@ -57,7 +58,7 @@ __host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, i
     n += (size_t)BLOCK_WAVES * (NSUM * cpg + 1) * 8;
     n += (size_t)(NSUM * bcap + 1) * 8;
     n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)3 * bcap * 8;
-    n += (size_t)2 * bcap * 4 + 16 + ((bcap + 15) & ~15u);
+    n += (size_t)2 * bcap * 4 + 32 + ((bcap + 15) & ~15u);
     n += (size_t)4 * HT_LDS * 8 + 128 * 8;
     return (n + 15) & ~(size_t)15;
 }
@@ -81,6 +82,7 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.flags = reinterpret_cast<uint32_t*>(q); q += 16;
+    sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
     sh.ada = q; q += (bcap + 15) & ~15u;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
     sh.red = reinterpret_cast<double*>(q);
@@ -126,6 +128,21 @@ __device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, con
     return m;
 }
 
+// Positions (relative to the cursor) t and t + BLOCK of the sweep order, flagged when the
+// marker's effect is non-zero at sweep start.  Loaded before the streaming loop.
+struct PivotScan {
+    uint32_t nz0, nz1;
+};
+
+__device__ __forceinline__ PivotScan load_pivot_scan(const SweepParams& p, const SweepDesc& d, int tid)
+{
+    PivotScan s{0u, 0u};
+    const uint32_t j0 = d.cursor + (uint32_t)tid, j1 = j0 + BLOCK;
+    if (j0 < p.M) s.nz0 = p.s_bold[j0] != 0.0 ? 1u : 0u;
+    if (j1 < p.M) s.nz1 = p.s_bold[j1] != 0.0 ? 1u : 0u;
+    return s;
+}
+
 // stage generator + normal tables in LDS (issued early as well)
 __device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShared& sh, int tid)
 {
@@ -144,7 +161,7 @@ __device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShare
 // has already run stage_rng() and load_marker_meta() and a __syncthreads().
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; sparse dot algebra :325-341.
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh,
-                                                 const MarkerMeta& mm)
+                                                 const MarkerMeta& mm, const PivotScan& scan)
 {
     const int tid = threadIdx.x;
     const int K = p.K;
@@ -310,6 +327,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                 n.nnz = d.nnz + 1;
             }
             sh.flags[1] = pos;
+            sh.flags[3] = naccept;
             n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
             n.launches = d.launches + 1;
             n.seq = d.seq + 1;
@@ -326,6 +344,27 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                 p.dbg[12] += naccept;
                 p.dbg[15] += 1;
             }
+        }
+    }
+    __syncthreads();
+    // width of the next batch: up to and including the first predicted event after the new cursor
+    {
+        const uint32_t nacc = sh.flags[3];
+        const uint32_t cap = p.batch_limit;
+        uint32_t cand = 0xffffffffu; // distance from the new cursor to this thread's first flagged position
+        if (scan.nz0 && (uint32_t)tid >= nacc) cand = (uint32_t)tid - nacc;
+        else if (scan.nz1 && (uint32_t)tid + BLOCK >= nacc) cand = (uint32_t)tid + BLOCK - nacc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 64);
+            cand = o < cand ? o : cand;
+        }
+        if ((tid & 63) == 0) sh.red_u[tid >> 6] = cand;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t best = sh.red_u[0];
+            for (int w = 1; w < BLOCK_WAVES; ++w) best = sh.red_u[w] < best ? sh.red_u[w] : best;
+            p.desc->batch = (best == 0xffffffffu || best + 1u > cap) ? cap : best + 1u;
         }
     }
     __syncthreads();
@@ -442,6 +481,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const uint32_t c1 = (c0 + CPG < nb) ? c0 + CPG : nb;
     const uint32_t ncol = (c1 > c0) ? c1 - c0 : 0u;
     const bool first_group = blockIdx.y == 0;
+    if (ncol == 0 && !first_group) return; // column group beyond this launch's batch: not part of the ticket
+    const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
     const double* eps_in = d.cur ? p.eps1 : p.eps0;
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
@@ -450,6 +491,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     // streaming loop (any of them may turn out to be the last arriver)
     const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
     if (!p.sums_out) stage_rng(p, sh, tid);
+    // markers whose effect is non-zero at sweep start WILL change (a predicted event): the next
+    // launch's batch is cut right after the first of them, so no dot is computed past it
+    const PivotScan scan = p.sums_out ? PivotScan{0u, 0u} : load_pivot_scan(p, d, tid);
     if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
@@ -552,7 +596,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        sh.flags[0] = (t == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+        sh.flags[0] = (t == gridDim.x * nactive - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (!sh.flags[0]) return;
@@ -615,7 +659,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
         }
         return;
     }
-    sweep_draw_phase(p, d, nb, sh, meta);
+    sweep_draw_phase(p, d, nb, sh, meta, scan);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
@@ -628,11 +672,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     const uint32_t nb = d.batch < remaining ? d.batch : remaining;
     if ((nb == 0 && !pend) || d.error) return;
     const MarkerMeta meta = load_marker_meta(p, d, nb, threadIdx.x);
+    const PivotScan scan = load_pivot_scan(p, d, threadIdx.x);
     stage_rng(p, sh, threadIdx.x);
     for (int r = threadIdx.x; r < NSUM * (int)nb; r += BLOCK) sh.tot[r] = p.sums_out[r];
     if (threadIdx.x == 0) sh.tot[NSUM * sh.bcap] = p.sums_out[NSUM * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase(p, d, nb, sh, meta);
+    sweep_draw_phase(p, d, nb, sh, meta, scan);
 }
 
 } // namespace hg

@@ -108,7 +108,7 @@ struct hgibbs_ctx {
     double* beta_host = nullptr;    // pinned, M doubles (lazy)
 
     // options
-    uint32_t batch = 0; // 0 = auto: 128 for shards of >= 200k individuals, else 64
+    uint32_t batch = 0; // 0 = auto: 256 for shards of >= 200k individuals or several ranks, else 128
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
@@ -982,7 +982,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipGetLastError());
 
     const uint32_t cpg = h->cols_per_group;
-    const uint32_t batch = h->batch ? h->batch : ((h->n_local >= 200000u || h->nranks > 1) ? 128u : 64u);
+    const uint32_t batch = h->batch ? h->batch : ((h->n_local >= 200000u || h->nranks > 1) ? 256u : 128u);
     const uint32_t ngroups = (batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
@@ -1032,6 +1032,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.nblk_x = h->n_pad / BLOCK_IND;
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
+    p.batch_limit = batch;
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
@@ -1046,8 +1047,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     }
 
     const uint32_t ntg = h->n_pad / BLOCK_IND;
-    // auto: at most 768 workgroups (3 per CU at the kernel's register budget) so the grid is co-resident
-    const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : std::min<uint32_t>(S_CAP, std::max<uint32_t>(1u, 768u / ngroups)), ntg);
+    const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
     const dim3 grid(S, ngroups);
     uint64_t total_launches = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
