@@ -52,22 +52,24 @@ constexpr int S_CAP = 64;                // max tile-group slices (gridDim.x): o
 constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
-constexpr int ROWS_CAP = NSUM * MAX_BATCH + 8; // partial rows per slice (padded)
+constexpr int NROW = 3;                  // rows per batch column: s1, s2, integer Gram term with the pivot
+constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // partial rows per slice (padded)
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
 struct SweepDesc {
-    uint32_t cursor;       // next position in order[]
-    int32_t pend_marker;   // marker whose eps update is still to be applied, -1 none
-    double pv[3];          // update constants for genotype 0,1,2 (missing gets 0)
-    uint32_t cur;          // which eps buffer is current
-    uint32_t batch;        // width of the next speculative batch
-    uint32_t rng_idx;      // MT19937 position (0..624)
-    uint32_t error;        // non-zero: logL overflow abort (src/BayesRRm.cpp:1910-1913) or rng buffer overrun
-    uint64_t nnz;          // markers with deltaBeta != 0 so far
-    uint64_t launches;     // launches that did work
-    uint64_t accepted_sum; // total accepted markers (== cursor at the end)
-    uint64_t seq;          // batches since the handle was created (epoch of the cross-GPU exchange)
+    uint32_t cursor;        // next position in order[]
+    uint32_t cur;           // which eps buffer is current
+    int32_t pend_marker[2]; // markers whose eps update is still to be applied (in order), -1 none
+    double pv[2][3];        // their update constants for genotype 0,1,2 (missing gets 0)
+    uint32_t batch;         // columns up to and including the pivot (first predicted event)
+    uint32_t batch2;        // all columns of the next launch; [batch, batch2) is the Gram-corrected extension
+    uint32_t rng_idx;       // MT19937 position (0..624)
+    uint32_t error;         // non-zero: 1 logL overflow abort (src/BayesRRm.cpp:1910-1913), 2 rng staging overrun, 3 peer timeout
+    uint64_t nnz;           // markers with deltaBeta != 0 so far
+    uint64_t launches;      // launches that did work
+    uint64_t accepted_sum;  // total accepted markers (== cursor at the end)
+    uint64_t seq;           // batches since the handle was created (epoch of the cross-GPU exchange)
 };
 
 // In-launch cross-GPU exchange (xGMI peer mailboxes, IPC-mapped).  Rank r's
@@ -88,6 +90,8 @@ struct SweepParams {
     uint32_t n_pad;        // padded local individuals
     uint32_t M;
     double n_minus_1;      // (double)(N_global - 1)
+    double n_total;        // (double)N_global
+    int gram;              // 1: extend batches past the first predicted event with Gram-corrected dots
     const double* mave;
     const double* mstd;
     const int32_t* groups;
@@ -123,7 +127,7 @@ struct SweepParams {
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)
     // multi-GPU: when non-null the kernel stops after the local reduction and
-    // leaves sums[NSUM*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
+    // leaves sums[NROW*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;
     unsigned long long* dbg; // optional stage timestamps (wall_clock64, 100 MHz)
     P2PParams p2p;

@@ -8,6 +8,7 @@
 namespace hg {
 
 #define HG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define HG_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
 // Word source over the two MT19937 blocks staged in LDS (untempered words).
 struct LdsGen {
@@ -32,34 +33,37 @@ struct SweepShared {
     double* zig_nx;    // 129 + 129: normal Ziggurat layers staged for the draw
     double* zig_ny;
     double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns (+ sum of eps)
-    double* tot;       // 3*bcap + 1 reduced sums
+    double* tot;       // NROW*bcap + 1 reduced sums
     double* thr;       // [bcap][K-1]
     double* muk;       // [bcap][K]
     double* logl;      // [bcap][K]
     double* bold;      // [bcap]
     double* mave;
     double* mstd;
+    double* dp;        // [bcap] x_j'eps as reduced from the dots (before corrections)
     int32_t* marker;
     int32_t* grp;
-    uint32_t* flags;   // [0] last-arriver flag, [1] stream position after the walk, [2] exchange timeout, [3] accepted
-    uint32_t* red_u;   // 4 words: block minimum of the predicted-event scan
+    uint32_t* flags;   // see F_* below
+    uint32_t* red_u;   // 4 words: block minimum scratch
     uint8_t* ada;
-    double* red;       // 128 doubles: exchange buffer of the tail reduction
     double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
-    uint32_t wstride;  // 3*cpg + 1
+    double* red;       // 128 doubles: exchange buffer of the tail reduction
+    double* ev;        // 8 doubles: event hand-off between the walk and the rest of the workgroup
+    uint32_t wstride;  // NROW*cpg + 1
     uint32_t bcap;     // batch capacity of this launch
 };
+enum { F_LAST = 0, F_POS = 1, F_P2PTMO = 2, F_NACC = 3, F_STOP = 4, F_FPOS = 5, F_FMARK = 6, F_ERR = 7 };
 
 __host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K)
 {
     size_t n = 0;
     n += MT_BUF * 4;
     n += 2 * 130 * 8;
-    n += (size_t)BLOCK_WAVES * (NSUM * cpg + 1) * 8;
-    n += (size_t)(NSUM * bcap + 1) * 8;
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)3 * bcap * 8;
-    n += (size_t)2 * bcap * 4 + 32 + ((bcap + 15) & ~15u);
-    n += (size_t)4 * HT_LDS * 8 + 128 * 8;
+    n += (size_t)BLOCK_WAVES * (NROW * cpg + 1) * 8;
+    n += (size_t)(NROW * bcap + 1) * 8;
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)4 * bcap * 8;
+    n += (size_t)2 * bcap * 4 + 32 + 16 + ((bcap + 15) & ~15u);
+    n += (size_t)4 * HT_LDS * 8 + 128 * 8 + 8 * 8;
     return (n + 15) & ~(size_t)15;
 }
 
@@ -70,22 +74,24 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
-    sh.wstride = NSUM * cpg + 1;
+    sh.wstride = NROW * cpg + 1;
     sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
-    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NSUM * bcap + 1) * 8;
+    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NROW * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.mave = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.mstd = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.dp = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
-    sh.flags = reinterpret_cast<uint32_t*>(q); q += 16;
+    sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
     sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
     sh.ada = q; q += (bcap + 15) & ~15u;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
-    sh.red = reinterpret_cast<double*>(q);
+    sh.red = reinterpret_cast<double*>(q); q += 128 * 8;
+    sh.ev = reinterpret_cast<double*>(q);
     sh.bcap = bcap;
     return sh;
 }
@@ -104,7 +110,7 @@ __device__ __forceinline__ void mt_next_block(uint32_t* mt, int tid)
 }
 
 // Per-thread marker metadata for the draw phase; loaded EARLY (before the
-// partial reduction) so that its dependent global loads overlap the reduction.
+// streaming loop) from the sweep-ordered side arrays: no dependent gather.
 struct MarkerMeta {
     int marker, grp;
     bool ada, miss;
@@ -115,7 +121,7 @@ __device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, con
 {
     MarkerMeta m{-1, 0, false, false, 0.0, 0.0, 0.0};
     if ((uint32_t)tid < nb) {
-        const uint32_t j = d.cursor + tid; // sweep-ordered side arrays: no dependent gather
+        const uint32_t j = d.cursor + tid;
         m.marker = p.order[j];
         const int ga = p.s_ga[j];
         m.grp = ga & 0x0fffffff;
@@ -128,22 +134,23 @@ __device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, con
     return m;
 }
 
-// Positions (relative to the cursor) t and t + BLOCK of the sweep order, flagged when the
-// marker's effect is non-zero at sweep start.  Loaded before the streaming loop.
+// Positions (relative to the cursor) t and t + BLOCK of the sweep order: bit 0 = the
+// marker's effect is non-zero at sweep start (it WILL change: a predicted event),
+// bit 1 = its column has missing calls.  Loaded before the streaming loop.
 struct PivotScan {
-    uint32_t nz0, nz1;
+    uint32_t f0, f1;
 };
 
 __device__ __forceinline__ PivotScan load_pivot_scan(const SweepParams& p, const SweepDesc& d, int tid)
 {
     PivotScan s{0u, 0u};
     const uint32_t j0 = d.cursor + (uint32_t)tid, j1 = j0 + BLOCK;
-    if (j0 < p.M) s.nz0 = p.s_bold[j0] != 0.0 ? 1u : 0u;
-    if (j1 < p.M) s.nz1 = p.s_bold[j1] != 0.0 ? 1u : 0u;
+    if (j0 < p.M) s.f0 = (p.s_bold[j0] != 0.0 ? 1u : 0u) | ((p.s_ga[j0] & 0x20000000) ? 2u : 0u);
+    if (j1 < p.M) s.f1 = (p.s_bold[j1] != 0.0 ? 1u : 0u) | ((p.s_ga[j1] & 0x20000000) ? 2u : 0u);
     return s;
 }
 
-// stage generator + normal tables in LDS (issued early as well)
+// stage generator + normal tables + hyper tables in LDS (issued early as well)
 __device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShared& sh, int tid)
 {
     for (int i = tid; i < MT_N; i += BLOCK) sh.mt[i] = p.mt[i];
@@ -155,13 +162,32 @@ __device__ __forceinline__ void stage_rng(const SweepParams& p, const SweepShare
         for (int i = tid; i < 4 * p.GK; i += BLOCK) sh.htab[(i / p.GK) * HT_LDS + (i % p.GK)] = p.denom[i]; // 4 tables are contiguous
 }
 
-// Posterior + draw + bookkeeping for the nb markers of this batch, given the
-// reduced sums in sh.tot: rows [2j,2j+1] = (s1,s2) of batch column j, last row
-// = sum of eps.  Runs in ONE workgroup of 256 threads; the caller
-// has already run stage_rng() and load_marker_meta() and a __syncthreads().
-// a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; sparse dot algebra :325-341.
-__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh,
-                                                 const MarkerMeta& mm, const PivotScan& scan)
+__device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_t v, int tid)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) sh.red_u[tid >> 6] = v;
+    __syncthreads();
+    uint32_t best = sh.red_u[0];
+    for (int w = 1; w < BLOCK_WAVES; ++w) best = sh.red_u[w] < best ? sh.red_u[w] : best;
+    return best;
+}
+
+// Posterior + draw + bookkeeping for the markers of this batch, given the reduced
+// sums in sh.tot: rows [3j, 3j+1, 3j+2] = (s1, s2, A) of batch column j, last row
+// = sum of eps.  A_j = sum_i gw_j gw_pivot (integer) for the columns of the
+// EXTENSION [nb1, nb2): those dots were taken before the pivot's (position
+// nb1-1, a predicted event) update and are corrected here once its new effect is
+// known:  x_j'eps_new = x_j'eps_old + dbeta_p * x_j'x_p,
+//         x_j'x_p = mstd_j mstd_p (A_j - N mave_j mave_p)   (columns without missing calls).
+// Runs in ONE workgroup of 256 threads.
+// a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
+__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb1, uint32_t nb2,
+                                                 const SweepShared& sh, const MarkerMeta& mm, const PivotScan& scan)
 {
     const int tid = threadIdx.x;
     const int K = p.K;
@@ -169,27 +195,48 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
     const bool need_next = idx0 + MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
     if (need_next) mt_next_block(sh.mt, tid);
 
-    // ---- per-marker posterior, one thread per batch column -----------------
-    if ((uint32_t)tid < nb) {
+    // per-column state -> LDS, dot products from the reduced rows
+    if ((uint32_t)tid < nb2) {
         sh.marker[tid] = mm.marker;
         sh.grp[tid] = mm.grp;
         sh.ada[tid] = mm.ada ? 1 : 0;
         sh.bold[tid] = mm.bold;
         sh.mave[tid] = mm.mave;
         sh.mstd[tid] = mm.mstd;
-        if (mm.ada) {
-            // dense BED form of the reference (src/BayesRRm.cpp:1785-1790,1809):
-            // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
-            // A column without missing calls has s2 == sum of eps, bit for bit
-            // (same lanes, same order), so it is not accumulated per column.
-            const double s1 = sh.tot[NSUM * tid];
-            const double s2 = mm.miss ? sh.tot[NSUM * tid + 1] : sh.tot[NSUM * sh.bcap];
-            const double dp = mm.mstd * (s1 - mm.mave * s2);
-            double num = dp;
-            num += mm.bold * p.n_minus_1;
+        // dense BED form of the reference (src/BayesRRm.cpp:1785-1790,1809):
+        // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
+        // A column without missing calls has s2 == sum of eps, bit for bit
+        // (same lanes, same order), so it is not accumulated per column.
+        const double s1 = sh.tot[NROW * tid];
+        const double s2 = mm.miss ? sh.tot[NROW * tid + 1] : sh.tot[NROW * sh.bcap];
+        sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
+    }
+    if (tid == 0) {
+        sh.flags[F_POS] = idx0;
+        sh.flags[F_NACC] = 0;
+        sh.flags[F_ERR] = 0;
+    }
+    __syncthreads();
 
-            // group's table rows into registers through typed (LDS or global) pointers: a
-            // pointer select would make every access a flat load with a full wait
+    // pending updates handed to the next launch
+    int pend_marker[2] = {-1, -1};
+    double pend_pv[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int npend = 0;
+    unsigned long long nnz_add = 0;
+
+    for (int seg = 0; seg < 2; ++seg) {
+        const uint32_t lo = seg ? nb1 : 0u, hi = seg ? nb2 : nb1;
+        if (lo >= hi) break; // uniform
+
+        // ---- posterior of [lo, hi), one thread per batch column -----------------
+        if ((uint32_t)tid >= lo && (uint32_t)tid < hi && mm.ada) {
+            double num = sh.dp[tid];
+            if (seg) { // Gram correction for the pivot's update
+                const double A = sh.tot[NROW * tid + 2];
+                const double xx = mm.mstd * sh.ev[2] * (A - p.n_total * (mm.mave * sh.ev[1]));
+                num += sh.ev[0] * xx;
+            }
+            num += mm.bold * p.n_minus_1;
             double den[MAX_K], lpi[MAX_K], hlg[MAX_K];
             if (p.GK <= HT_LDS) {
                 for (int k = 0; k < K; ++k) {
@@ -212,176 +259,220 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                 sh.logl[tid * K + k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
             }
         }
-    }
-    __syncthreads();
-    // increments of the component walk (:1883-1921), one thread per (marker, component):
-    // q[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)
-    for (uint32_t it = tid; it < nb * (uint32_t)(K - 1); it += BLOCK) {
-        const uint32_t j = it / (uint32_t)(K - 1), kk = it % (uint32_t)(K - 1);
-        if (!sh.ada[j]) continue;
-        const double* L = sh.logl + j * K;
-        const double base = L[kk];
-        bool big = false;
-        for (int l = (kk ? (int)kk : 1); l < K; ++l)
-            if (fabs(L[l] - base) > 700.0) big = true;
-        double q = 0.0;
-        if (!big) {
-            double sum = 0.0;
-            for (int l = 0; l < K; ++l) sum += exp(L[l] - base);
-            q = 1.0 / sum;
+        __syncthreads();
+        // increments of the component walk (:1883-1921), one thread per (marker, component):
+        // q[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)
+        for (uint32_t it = tid; it < (hi - lo) * (uint32_t)(K - 1); it += BLOCK) {
+            const uint32_t j = lo + it / (uint32_t)(K - 1), kk = it % (uint32_t)(K - 1);
+            if (!sh.ada[j]) continue;
+            const double* L = sh.logl + j * K;
+            const double base = L[kk];
+            bool big = false;
+            for (int l = (kk ? (int)kk : 1); l < K; ++l)
+                if (fabs(L[l] - base) > 700.0) big = true;
+            double q = 0.0;
+            if (!big) {
+                double sum = 0.0;
+                for (int l = 0; l < K; ++l) sum += exp(L[l] - base);
+                q = 1.0 / sum;
+            }
+            sh.thr[j * (K - 1) + kk] = q;
         }
-        sh.thr[j * (K - 1) + kk] = q;
-    }
-    __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[3] = wall_clock64();
+        __syncthreads();
+        if (p.dbg && tid == 0 && seg == 0) p.dbg[3] = wall_clock64();
 
-    // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
-    if (tid < WAVE) {
-        const int lane = tid;
-        uint32_t pos = idx0;       // stream position (words consumed so far = pos - idx0)
-        uint32_t naccept = 0;      // markers accepted so far
-        int f_marker = -1;
-        double f_dbeta = 0.0, f_mave = 0.0, f_mstd = 0.0;
-        uint32_t f_err = 0;
-        bool stopped = false;
-        for (uint32_t base = 0; base < nb && !stopped; base += WAVE) {
-            const uint32_t j = base + lane;
-            const bool valid = j < nb;
-            const bool ada = valid && sh.ada[valid ? j : 0] != 0;
-            const double bold = valid ? sh.bold[j] : 0.0;
-            const int grp = valid ? sh.grp[j] : 0;
-            const int marker = valid ? sh.marker[j] : -1;
-            const unsigned long long am = __ballot(ada);
-            const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-            int k = 0;
-            if (ada) {
-                const uint32_t u = mt_temper(sh.mt[pos + jeff]);
-                const double prob = (double)u * (1.0 / 4294967296.0);
-                k = K - 1;
-                double acum = 0.0; // acum_k = q_0 + ... + q_k, added in the reference's order
-                bool found = false;
-                for (int kk = 0; kk + 1 < K; ++kk) {
-                    acum = kk ? acum + sh.thr[j * (K - 1) + kk] : sh.thr[j * (K - 1)];
-                    if (!found && prob <= acum) {
-                        k = kk;
-                        found = true;
+        // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
+        if (tid < WAVE) {
+            const int lane = tid;
+            uint32_t pos = sh.flags[F_POS]; // stream position
+            uint32_t naccept = 0;
+            bool stopped = false;
+            for (uint32_t base = lo; base < hi && !stopped; base += WAVE) {
+                const uint32_t j = base + lane;
+                const bool valid = j < hi;
+                const bool ada = valid && sh.ada[valid ? j : 0] != 0;
+                const double bold = valid ? sh.bold[j] : 0.0;
+                const int grp = valid ? sh.grp[j] : 0;
+                const int marker = valid ? sh.marker[j] : -1;
+                const unsigned long long am = __ballot(ada);
+                const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                int k = 0;
+                if (ada) {
+                    const uint32_t u = mt_temper(sh.mt[pos + jeff]);
+                    const double prob = (double)u * (1.0 / 4294967296.0);
+                    k = K - 1;
+                    double acum = 0.0; // acum_k = q_0 + ... + q_k, added in the reference's order
+                    bool found = false;
+                    for (int kk = 0; kk + 1 < K; ++kk) {
+                        acum = kk ? acum + sh.thr[j * (K - 1) + kk] : sh.thr[j * (K - 1)];
+                        if (!found && prob <= acum) {
+                            k = kk;
+                            found = true;
+                        }
+                    }
+                }
+                const bool event = valid && (ada ? (k != 0 || bold != 0.0) : (bold != 0.0));
+                const unsigned long long em = __ballot(event);
+                const uint32_t nvalid = (hi - base < (uint32_t)WAVE) ? hi - base : (uint32_t)WAVE;
+                const uint32_t f = em ? (uint32_t)(__ffsll((long long)em) - 1) : nvalid; // first event in this chunk
+                const uint32_t nacc = (f < nvalid) ? f + 1 : nvalid;
+
+                double bnew = 0.0;
+                uint32_t consumed = 0, gerr = 0;
+                if ((uint32_t)lane == f && ada && k > 0) {
+                    LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
+                    ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
+                    const double sd = (p.GK <= HT_LDS) ? sh.htab[3 * HT_LDS + grp * K + k] : p.sdk[(size_t)grp * K + k];
+                    bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], sd);
+                    consumed = g.pos - (pos + jeff + 1u);
+                    gerr = g.err;
+                }
+                const double dbeta = bold - bnew;
+
+                // results of accepted markers (:1892,:1899-1905,:1924-1925)
+                if ((uint32_t)lane < nacc) {
+                    if (ada) {
+                        const int kk = ((uint32_t)lane == f) ? k : 0;
+                        p.beta[marker] = ((uint32_t)lane == f) ? bnew : 0.0;
+                        p.comp[marker] = kk;
+                        p.acum[marker] = sh.thr[j * (K - 1)];
+                        atomicAdd(&p.cass[grp * K + kk], 1);
+                    } else {
+                        p.beta[marker] = 0.0;
+                        p.acum[marker] = 1.0;
+                    }
+                }
+                const uint32_t used = (uint32_t)__popcll(am & ((nacc >= 64u) ? ~0ull : ((1ull << nacc) - 1ull)));
+                naccept += nacc;
+                pos += used;
+                if (f < nvalid) { // an event ends the segment (later dots are stale)
+                    stopped = true;
+                    const int src = (int)f;
+                    const double f_dbeta = __shfl(dbeta, src, 64);
+                    const int f_marker = __shfl(marker, src, 64);
+                    pos += (uint32_t)__shfl((int)consumed, src, 64);
+                    const uint32_t f_err = (uint32_t)__shfl((int)gerr, src, 64);
+                    if (lane == 0) {
+                        sh.ev[0] = f_dbeta;
+                        sh.ev[1] = sh.mave[base + f];
+                        sh.ev[2] = sh.mstd[base + f];
+                        sh.flags[F_FPOS] = base + f;
+                        sh.flags[F_FMARK] = (uint32_t)f_marker;
+                        if (f_err) sh.flags[F_ERR] = f_err;
                     }
                 }
             }
-            const bool event = valid && (ada ? (k != 0 || bold != 0.0) : (bold != 0.0));
-            const unsigned long long em = __ballot(event);
-            const uint32_t nvalid = (nb - base < (uint32_t)WAVE) ? nb - base : (uint32_t)WAVE;
-            const uint32_t f = em ? (uint32_t)(__ffsll((long long)em) - 1) : nvalid; // first event in this chunk
-            const uint32_t nacc = (f < nvalid) ? f + 1 : nvalid;
-
-            double bnew = 0.0;
-            uint32_t consumed = 0, gerr = 0;
-            if ((uint32_t)lane == f && ada && k > 0) {
-                LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
-                ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
-                const double sd = (p.GK <= HT_LDS) ? sh.htab[3 * HT_LDS + grp * K + k] : p.sdk[(size_t)grp * K + k];
-                bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], sd);
-                consumed = g.pos - (pos + jeff + 1u);
-                gerr = g.err;
-            }
-            const double dbeta = bold - bnew;
-
-            // results of accepted markers (:1892,:1899-1905,:1924-1925)
-            if ((uint32_t)lane < nacc) {
-                if (ada) {
-                    const int kk = ((uint32_t)lane == f) ? k : 0;
-                    p.beta[marker] = ((uint32_t)lane == f) ? bnew : 0.0;
-                    p.comp[marker] = kk;
-                    p.acum[marker] = sh.thr[j * (K - 1)];
-                    atomicAdd(&p.cass[grp * K + kk], 1);
-                } else {
-                    p.beta[marker] = 0.0;
-                    p.acum[marker] = 1.0;
-                }
-            }
-            const uint32_t used = (uint32_t)__popcll(am & ((nacc >= 64u) ? ~0ull : ((1ull << nacc) - 1ull)));
-            naccept += nacc;
-            pos += used;
-            if (f < nvalid) { // an event ends the batch (later dots are stale)
-                stopped = true;
-                const int src = (int)f;
-                f_dbeta = __shfl(dbeta, src, 64);
-                f_marker = __shfl(marker, src, 64);
-                f_mave = sh.mave[base + f];
-                f_mstd = sh.mstd[base + f];
-                pos += (uint32_t)__shfl((int)consumed, src, 64);
-                f_err = (uint32_t)__shfl((int)gerr, src, 64);
+            if (lane == 0) {
+                sh.flags[F_POS] = pos;
+                sh.flags[F_NACC] += naccept;
+                sh.flags[F_STOP] = stopped ? 1u : 0u;
             }
         }
-        // hand the state to the next launch
-        if (lane == 0) {
-            SweepDesc n = d;
-            n.cursor = d.cursor + naccept;
-            if (d.pend_marker >= 0) n.cur = d.cur ^ 1u;
-            n.pend_marker = -1;
-            if (stopped && f_dbeta != 0.0) {
-                n.pend_marker = f_marker;
-                n.pv[0] = -(f_mave * f_mstd * f_dbeta);
-                n.pv[1] = f_dbeta * (1.0 - f_mave) * f_mstd;
-                n.pv[2] = f_dbeta * (2.0 - f_mave) * f_mstd;
-                n.nnz = d.nnz + 1;
+        __syncthreads();
+
+        // an event: its update is pending for the next launch
+        const bool stopped = sh.flags[F_STOP] != 0;
+        if (stopped) {
+            const double db = sh.ev[0], av = sh.ev[1], sd = sh.ev[2];
+            if (db != 0.0) {
+                pend_marker[npend] = (int)sh.flags[F_FMARK];
+                pend_pv[npend][0] = -(av * sd * db);
+                pend_pv[npend][1] = db * (1.0 - av) * sd;
+                pend_pv[npend][2] = db * (2.0 - av) * sd;
+                ++npend;
+                ++nnz_add;
             }
-            sh.flags[1] = pos;
-            sh.flags[3] = naccept;
-            n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
-            n.launches = d.launches + 1;
-            n.seq = d.seq + 1;
-            n.accepted_sum = d.accepted_sum + naccept;
-            if (f_err) n.error = f_err;
-            *p.desc = n;
-            if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
-                p.dbg[4] = wall_clock64();
-                for (int i = 0; i < 4; ++i) p.dbg[8 + i] += p.dbg[i + 1] - p.dbg[i];
-                p.dbg[13] += p.dbg[6] - p.dbg[5]; // last arriver: entry -> loop done
-                p.dbg[14] += p.dbg[7] - p.dbg[6]; // last arriver: loop done -> drained
-                p.dbg[16] += p.dbg[1] - p.dbg[7]; // last arriver: drained -> past ticket
-                p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
-                p.dbg[12] += naccept;
-                p.dbg[15] += 1;
-            }
+        }
+        // go on into the extension only if segment 0 ran to its end and ended ON the pivot
+        if (!(seg == 0 && stopped && sh.flags[F_FPOS] == nb1 - 1u && nb2 > nb1)) break;
+        __syncthreads(); // sh.ev stays valid for the corrections; flags are rewritten by the next walk
+    }
+
+    // ---- hand the state to the next launch ---------------------------------------
+    const uint32_t naccept = sh.flags[F_NACC];
+    const uint32_t pos = sh.flags[F_POS];
+    if (tid == 0) {
+        SweepDesc n = d;
+        n.cursor = d.cursor + naccept;
+        if (d.pend_marker[0] >= 0) n.cur = d.cur ^ 1u;
+        for (int q = 0; q < 2; ++q) {
+            n.pend_marker[q] = pend_marker[q];
+            for (int c = 0; c < 3; ++c) n.pv[q][c] = pend_pv[q][c];
+        }
+        n.nnz = d.nnz + nnz_add;
+        n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
+        n.launches = d.launches + 1;
+        n.seq = d.seq + 1;
+        n.accepted_sum = d.accepted_sum + naccept;
+        if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
+        *p.desc = n;
+        if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
+            p.dbg[4] = wall_clock64();
+            for (int i = 0; i < 4; ++i) p.dbg[8 + i] += p.dbg[i + 1] - p.dbg[i];
+            p.dbg[13] += p.dbg[6] - p.dbg[5]; // last arriver: entry -> loop done
+            p.dbg[14] += p.dbg[7] - p.dbg[6]; // last arriver: loop done -> drained
+            p.dbg[16] += p.dbg[1] - p.dbg[7]; // last arriver: drained -> past ticket
+            p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
+            p.dbg[12] += naccept;
+            p.dbg[15] += 1;
         }
     }
-    __syncthreads();
-    // width of the next batch: up to and including the first predicted event after the new cursor
+
+    // ---- plan of the next launch ---------------------------------------------------
+    // batch  = up to and including the first predicted event after the new cursor (the pivot);
+    // batch2 = further up to and including the NEXT predicted event, as long as the columns
+    //          involved have no missing calls (their dots get the Gram correction above).
     {
-        const uint32_t nacc = sh.flags[3];
         const uint32_t cap = p.batch_limit;
-        uint32_t cand = 0xffffffffu; // distance from the new cursor to this thread's first flagged position
-        if (scan.nz0 && (uint32_t)tid >= nacc) cand = (uint32_t)tid - nacc;
-        else if (scan.nz1 && (uint32_t)tid + BLOCK >= nacc) cand = (uint32_t)tid + BLOCK - nacc;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 64);
-            cand = o < cand ? o : cand;
+        const uint32_t q0 = (uint32_t)tid, q1 = (uint32_t)tid + BLOCK; // positions relative to the old cursor
+        uint32_t cand = 0xffffffffu;
+        if ((scan.f0 & 1u) && q0 >= naccept) cand = q0 - naccept;
+        else if ((scan.f1 & 1u) && q1 >= naccept) cand = q1 - naccept;
+        const uint32_t p1 = block_min_u32(sh, cand, tid); // distance of the pivot from the new cursor
+        uint32_t want1 = cap, want2 = cap;
+        if (p1 != 0xffffffffu && p1 + 1u <= cap) {
+            want1 = p1 + 1u;
+            // is the pivot's own column free of missing calls?
+            uint32_t pm = 0xffffffffu;
+            if (q0 == naccept + p1) pm = (scan.f0 >> 1) & 1u;
+            if (q1 == naccept + p1) pm = (scan.f1 >> 1) & 1u;
+            const uint32_t pivot_miss = block_min_u32(sh, pm, tid);
+            // first later position that ends the extension: a predicted event or a column with missing calls
+            uint32_t c2 = 0xffffffffu, c2m = 0u;
+            if (q0 > naccept + p1 && scan.f0) {
+                c2 = q0 - naccept;
+                c2m = (scan.f0 >> 1) & 1u;
+            } else if (q1 > naccept + p1 && scan.f1) {
+                c2 = q1 - naccept;
+                c2m = (scan.f1 >> 1) & 1u;
+            }
+            const uint32_t e = block_min_u32(sh, c2, tid);
+            uint32_t em = 0xffffffffu;
+            if (c2 == e && e != 0xffffffffu) em = c2m;
+            const uint32_t e_miss = block_min_u32(sh, em, tid);
+            if (!p.gram || pivot_miss != 0u) want2 = want1;
+            else if (e == 0xffffffffu) want2 = cap;
+            else want2 = e_miss ? e : e + 1u; // a column with missing calls stays out of the extension
+            if (want2 > cap) want2 = cap;
+            if (want2 < want1) want2 = want1;
         }
-        if ((tid & 63) == 0) sh.red_u[tid >> 6] = cand;
-        __syncthreads();
         if (tid == 0) {
-            uint32_t best = sh.red_u[0];
-            for (int w = 1; w < BLOCK_WAVES; ++w) best = sh.red_u[w] < best ? sh.red_u[w] : best;
-            p.desc->batch = (best == 0xffffffffu || best + 1u > cap) ? cap : best + 1u;
+            p.desc->batch = want1;
+            p.desc->batch2 = want2;
         }
     }
     __syncthreads();
     // generator crossed into the next block: make it the current one
-    if (sh.flags[1] >= (uint32_t)MT_N)
+    if (pos >= (uint32_t)MT_N)
         for (int i = tid; i < MT_N; i += BLOCK) p.mt[i] = sh.mt[MT_N + i];
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hg_smem[];
 
-#define HG_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
-
 // Inner step of the dot product for one slot S of four columns: field extract,
 // int -> f64, fused multiply-add, issued as three groups of four so that the
 // in-order SIMD always has three independent instructions between a producer and
-// its consumer (hipcc serialises the plain C++ form through one temporary).
-// a += double((g >> 2S) & 3) * e  -- the product is exact, one rounding per add.
+// its consumer.  a += double((g >> 2S) & 3) * e  -- the product is exact, one rounding per add.
 template <int S>
 __device__ __forceinline__ void fma_slot4(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, double e, double& a0, double& a1,
                                           double& a2, double& a3)
@@ -412,6 +503,14 @@ __device__ __forceinline__ void fma_slots4(uint32_t g0, uint32_t g1, uint32_t g2
     (fma_slot4<S>(g0, g1, g2, g3, e[S], a0, a1, a2, a3), ...);
 }
 
+// sum over the 16 slots of gw_a * gw_b (2-bit fields with values 0,1,2): integer Gram term
+__device__ __forceinline__ uint32_t gram16(uint32_t ga, uint32_t gb)
+{
+    const uint32_t la = ga & 0x55555555u, ha = (ga >> 1) & 0x55555555u;
+    const uint32_t lb = gb & 0x55555555u, hb = (gb >> 1) & 0x55555555u;
+    return (uint32_t)__popc(la & lb) + 2u * (uint32_t)(__popc(la & hb) + __popc(ha & lb)) + 4u * (uint32_t)__popc(ha & hb);
+}
+
 // Cross-GPU sum of the batch rows held in sh.tot, inside the launch: push my
 // rows into every rank's mailbox (system-scope stores over xGMI), publish one
 // flag per destination, wait for the nranks flags in my own mailbox, then add
@@ -422,13 +521,13 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDe
 {
     const int tid = threadIdx.x;
     const int nr = p.p2p.nranks, me = p.p2p.rank;
-    const uint32_t nrows = NSUM * nb + 1;
+    const uint32_t nrows = NROW * nb + 1;
     const uint32_t parity = (uint32_t)(d.seq & 1ull);
     const unsigned long long epoch = d.seq + 1ull;
     const size_t slot = (size_t)(parity * MAX_RANKS + (uint32_t)me) * ROWS_CAP;
     for (uint32_t it = tid; it < nrows * (uint32_t)nr; it += BLOCK) {
         const uint32_t dst = it / nrows, rr = it % nrows;
-        const double v = sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr];
+        const double v = sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr];
         __hip_atomic_store(p.p2p.data[dst] + slot + rr, v, HG_RLX_SYSTEM);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -447,33 +546,35 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDe
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    if (!ok) sh.flags[2] = 1u;
+    if (!ok) sh.flags[F_P2PTMO] = 1u;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __syncthreads();
-    if (sh.flags[2]) return false;
+    if (sh.flags[F_P2PTMO]) return false;
     for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
         double acc = 0.0;
         for (int r = 0; r < nr; ++r)
             acc += __hip_atomic_load(p.p2p.data[me] + (size_t)(parity * MAX_RANKS + (uint32_t)r) * ROWS_CAP + rr, HG_RLX_SYSTEM);
-        sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr] = acc;
+        sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr] = acc;
     }
     __syncthreads();
     return true;
 }
 
-// One launch of the sweep.  grid = (S, ceil(batch/cols_per_group)): blockIdx.y
-// owns a group of up to CPG batch columns, blockIdx.x a strided set of tile
-// groups (4 wave tiles = 4096 individuals each).  Every lane keeps the masked
-// sums of its columns in registers across all its tiles; one wave/block
-// reduction per launch, then S_CAP-strided partial rows for the last arriver.
+// One launch of the sweep.  grid = (S, ceil(batch_limit/CPG)): blockIdx.y owns a
+// group of up to CPG batch columns, blockIdx.x a strided set of tile groups
+// (4 wave tiles = 4096 individuals each).  Every lane keeps the sums of its
+// columns in registers across all its tiles; one wave/block reduction per
+// launch, then per-slice partial rows for the last arriver.
 template <int CPG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
 {
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
     const SweepDesc d = *p.desc;
-    const bool pend = d.pend_marker >= 0;
+    const bool pend = d.pend_marker[0] >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
-    const uint32_t nb = d.batch < remaining ? d.batch : remaining;
+    const uint32_t nb2 = d.batch2 < remaining ? d.batch2 : remaining; // all columns of this launch
+    const uint32_t nb1 = d.batch < nb2 ? d.batch : nb2;               // ... of which [nb1, nb2) are the extension
+    const uint32_t nb = nb2;
     if ((nb == 0 && !pend) || d.error) return; // whole grid agrees: nothing left to do
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,28 +592,37 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     // streaming loop (any of them may turn out to be the last arriver)
     const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
     if (!p.sums_out) stage_rng(p, sh, tid);
-    // markers whose effect is non-zero at sweep start WILL change (a predicted event): the next
-    // launch's batch is cut right after the first of them, so no dot is computed past it
     const PivotScan scan = p.sums_out ? PivotScan{0u, 0u} : load_pivot_scan(p, d, tid);
     if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
     unsigned long long t_loop = 0ull;
     double a1[CPG], a2[CPG], sall = 0.0;
+    uint32_t ag[CPG]; // integer Gram partial with the pivot column (extension columns only)
 #pragma unroll
-    for (int c = 0; c < CPG; ++c) a1[c] = a2[c] = 0.0;
+    for (int c = 0; c < CPG; ++c) {
+        a1[c] = a2[c] = 0.0;
+        ag[c] = 0u;
+    }
     const uint8_t* colp[CPG];
     bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
+    bool cgram[CPG]; // wave-uniform: column lies in the extension -> needs its Gram term with the pivot
+    bool any_gram = false;
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
         const int marker = nb ? p.order[d.cursor + j] : 0;
         cmiss[c] = nb ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
+        cgram[c] = (c0 + c < nb) && (c0 + c >= nb1) && nb1 > 0;
+        any_gram = any_gram || cgram[c];
         colp[c] = p.bed + (size_t)marker * p.stride + (lane << 2);
     }
-    const uint8_t* pendp = p.bed + (size_t)(pend ? d.pend_marker : 0) * p.stride + (lane << 2);
+    const uint8_t* pivp = p.bed + (size_t)(any_gram ? p.order[d.cursor + nb1 - 1] : 0) * p.stride + (lane << 2);
+    const uint8_t* pendp0 = p.bed + (size_t)(pend ? d.pend_marker[0] : 0) * p.stride + (lane << 2);
+    const bool pend1 = d.pend_marker[1] >= 0;
+    const uint8_t* pendp1 = p.bed + (size_t)(pend1 ? d.pend_marker[1] : 0) * p.stride + (lane << 2);
 
-    if (ncol || first_group) {
+    {
         for (uint32_t tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             double e[IPT];
@@ -520,9 +630,18 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             uint32_t w[CPG];
 #pragma unroll
             for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8));
-            if (pend) {
-                const uint32_t wp = *reinterpret_cast<const uint32_t*>(pendp + ((size_t)tile << 8));
-                apply_update16(wp, d.pv[0], d.pv[1], d.pv[2], e);
+            uint32_t gwp = 0;
+            if (any_gram) {
+                uint32_t nmp;
+                code_weights(*reinterpret_cast<const uint32_t*>(pivp + ((size_t)tile << 8)), gwp, nmp);
+            }
+            if (pend) { // the previous launch's event(s), in order
+                const uint32_t wp0 = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tile << 8));
+                apply_update16(wp0, d.pv[0][0], d.pv[0][1], d.pv[0][2], e);
+                if (pend1) {
+                    const uint32_t wp1 = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tile << 8));
+                    apply_update16(wp1, d.pv[1][0], d.pv[1][1], d.pv[1][2], e);
+                }
                 if (first_group) store_eps16(eps_out, tile, lane, e);
             }
             if (first_group) {
@@ -532,9 +651,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             uint32_t gw[CPG], nm[CPG];
 #pragma unroll
             for (int c = 0; c < CPG; ++c) code_weights(w[c], gw[c], nm[c]);
-            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add.  Slot-major order
-            // so that consecutive instructions feed CPG independent accumulator chains
-            // (each column still adds its slots in increasing order).
+            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds
+            // its slots in increasing order
             if constexpr (CPG % 4 == 0) {
 #pragma unroll
                 for (int c0g = 0; c0g < CPG; c0g += 4)
@@ -553,6 +671,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
 #pragma unroll
                     for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
                 }
+                if (cgram[c]) ag[c] += gram16(gw[c], gwp);
             }
         }
         t_loop = p.dbg ? wall_clock64() : 0ull;
@@ -560,35 +679,37 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
             const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
+            const double tg = any_gram ? wave_sum((double)ag[c]) : 0.0; // exact: integers far below 2^53
             if (lane == 0) {
-                sh.wpart[wave * sh.wstride + NSUM * c] = t1;
-                sh.wpart[wave * sh.wstride + NSUM * c + 1] = t2;
+                sh.wpart[wave * sh.wstride + NROW * c] = t1;
+                sh.wpart[wave * sh.wstride + NROW * c + 1] = t2;
+                sh.wpart[wave * sh.wstride + NROW * c + 2] = tg;
             }
         }
         if (first_group) {
             const double t = wave_sum(sall);
-            if (lane == 0) sh.wpart[wave * sh.wstride + NSUM * CPG] = t;
+            if (lane == 0) sh.wpart[wave * sh.wstride + NROW * CPG] = t;
         }
     }
     __syncthreads();
 
     // block partial = waves 0..3 in order, published write-through (sc1)
     {
-        const uint32_t nrow = NSUM * ncol;
+        const uint32_t nrow = NROW * ncol;
         for (uint32_t t = tid; t < nrow; t += BLOCK) {
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + (NSUM * c0 + t), v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + (NROW * c0 + t), v, HG_RLX_AGENT);
         }
         if (first_group && tid == BLOCK - 1) {
-            const uint32_t t = NSUM * CPG;
+            const uint32_t t = NROW * CPG;
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + NSUM * MAX_BATCH, v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + NROW * MAX_BATCH, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
@@ -596,10 +717,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        sh.flags[0] = (t == gridDim.x * nactive - 1u) ? 1u : 0u;
+        sh.flags[F_LAST] = (t == gridDim.x * nactive - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!sh.flags[0]) return;
+    if (!sh.flags[F_LAST]) return;
 
     // ---- last-arriving workgroup ---------------------------------------------
     if (p.dbg && tid == 0) {
@@ -614,13 +735,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     // 0..127 sum slices 0..31 of row t, threads 128..255 slices 32..63 (all 32
     // loads in flight); row total = (slices 0..31) + (slices 32..63).
     {
-        const uint32_t nrows = NSUM * nb + 1;
+        const uint32_t nrows = NROW * nb + 1;
         const uint32_t S = gridDim.x;
         const uint32_t half = tid >> 7, rl = tid & 127u;
         for (uint32_t rr0 = 0; rr0 < nrows; rr0 += 128) {
             const uint32_t rr = rr0 + rl;
             const bool live = rr < nrows;
-            const uint32_t r = (rr == NSUM * nb) ? NSUM * MAX_BATCH : rr;
+            const uint32_t r = (rr == NROW * nb) ? NROW * MAX_BATCH : rr;
             const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
             double v[32];
 #pragma unroll
@@ -631,16 +752,17 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             if (rr0) __syncthreads(); // previous round's exchange buffer is free again
             if (half == 1) sh.red[rl] = acc;
             __syncthreads();
-            if (live && half == 0) sh.tot[(rr == NSUM * nb) ? NSUM * sh.bcap : rr] = acc + sh.red[rl];
+            if (live && half == 0) sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr] = acc + sh.red[rl];
         }
     }
-    if (tid == 0) __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
+        sh.flags[F_P2PTMO] = 0u;
+    }
     __syncthreads();
     if (p.dbg && tid == 0) p.dbg[2] = wall_clock64();
 
     if (p.p2p.nranks > 1 && !p.sums_out) { // multi-GPU, in-launch exchange
-        if (tid == 0) sh.flags[2] = 0u;
-        __syncthreads();
         if (!p2p_exchange(p, d, nb, sh)) {
             if (tid == 0) {
                 SweepDesc n = d;
@@ -651,15 +773,15 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
         }
     }
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
-        for (int r = tid; r < NSUM * MAX_BATCH + 1; r += BLOCK) {
+        for (int r = tid; r < NROW * MAX_BATCH + 1; r += BLOCK) {
             double v = 0.0;
-            if (r < NSUM * (int)nb) v = sh.tot[r];
-            if (r == NSUM * MAX_BATCH) v = sh.tot[NSUM * sh.bcap];
+            if (r < NROW * (int)nb) v = sh.tot[r];
+            if (r == NROW * MAX_BATCH) v = sh.tot[NROW * sh.bcap];
             p.sums_out[r] = v;
         }
         return;
     }
-    sweep_draw_phase(p, d, nb, sh, meta, scan);
+    sweep_draw_phase(p, d, nb1, nb2, sh, meta, scan);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
@@ -667,17 +789,18 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
     const SweepDesc d = *p.desc;
-    const bool pend = d.pend_marker >= 0;
+    const bool pend = d.pend_marker[0] >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
-    const uint32_t nb = d.batch < remaining ? d.batch : remaining;
-    if ((nb == 0 && !pend) || d.error) return;
-    const MarkerMeta meta = load_marker_meta(p, d, nb, threadIdx.x);
+    const uint32_t nb2 = d.batch2 < remaining ? d.batch2 : remaining;
+    const uint32_t nb1 = d.batch < nb2 ? d.batch : nb2;
+    if ((nb2 == 0 && !pend) || d.error) return;
+    const MarkerMeta meta = load_marker_meta(p, d, nb2, threadIdx.x);
     const PivotScan scan = load_pivot_scan(p, d, threadIdx.x);
     stage_rng(p, sh, threadIdx.x);
-    for (int r = threadIdx.x; r < NSUM * (int)nb; r += BLOCK) sh.tot[r] = p.sums_out[r];
-    if (threadIdx.x == 0) sh.tot[NSUM * sh.bcap] = p.sums_out[NSUM * MAX_BATCH];
+    for (int r = threadIdx.x; r < NROW * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
+    if (threadIdx.x == 0) sh.tot[NROW * sh.bcap] = p.sums_out[NROW * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase(p, d, nb, sh, meta, scan);
+    sweep_draw_phase(p, d, nb1, nb2, sh, meta, scan);
 }
 
 } // namespace hg

@@ -112,6 +112,7 @@ struct hgibbs_ctx {
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
+    bool gram = true; // Gram-corrected continuation past the first predicted event
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
     hgibbs_sweep_stats stats{};
@@ -461,7 +462,7 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
     HIP_TRY(hipMalloc(&h->ticket, 64));
     HIP_TRY(hipMemset(h->ticket, 0, 64));
-    HIP_TRY(hipMalloc(&h->sums, (NSUM * MAX_BATCH + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&h->dbg, 24 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 24 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
@@ -905,6 +906,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "gram")) {
+        h->gram = value != 0;
     } else if (!std::strcmp(name, "p2p")) {
         h->p2p_enabled = value != 0;
     } else if (!std::strcmp(name, "force_split")) {
@@ -986,9 +989,10 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const uint32_t ngroups = (batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
-    d0.pend_marker = -1;
+    d0.pend_marker[0] = d0.pend_marker[1] = -1;
     d0.cur = h->eps_cur;
     d0.batch = batch;
+    d0.batch2 = batch;
     d0.rng_idx = rng->idx;
     d0.seq = h->batch_seq;
     *h->desc_host = d0;
@@ -1003,6 +1007,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.n_pad = h->n_pad;
     p.M = M;
     p.n_minus_1 = dNm1;
+    p.n_total = (double)h->n_global;
+    p.gram = h->gram ? 1 : 0;
     p.mave = h->mave;
     p.mstd = h->mstd;
     p.groups = h->groups;
@@ -1064,7 +1070,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             default: k_sweep_batch<16><<<grid, BLOCK, lds, h->stream>>>(p); break;
             }
             if (split) {
-                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, NSUM * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, NROW * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
                 k_sweep_draw<<<1, BLOCK, lds, h->stream>>>(p);
             }
         }
@@ -1074,7 +1080,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out)", dh.error, dh.cursor);
         if (dh.launches > 0) avg_accept = std::max(1.0, (double)dh.accepted_sum / (double)dh.launches);
-        if (dh.cursor >= M && dh.pend_marker < 0) break;
+        if (dh.cursor >= M && dh.pend_marker[0] < 0) break;
     }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));

@@ -158,14 +158,18 @@ def test_chain_vs_oracle_long(oracle):
                          batch=32, iters=10, missing_rate=0.0)
 
 
-def test_batch_width_does_not_change_the_chain():
-    """Speculative batching is exact: any batch width gives bit-identical output."""
-    bed, y = make_case(500, 3000, seed=99)
+@pytest.mark.parametrize("missing_rate", [0.0, 0.02])
+def test_batch_width_does_not_change_the_chain(missing_rate):
+    """Plain speculative batching is exact: with the Gram-corrected extension off
+    every batch width gives bit-identical output (each accepted marker saw the
+    residual the sequential loop would have given it)."""
+    bed, y = make_case(500, 3000, seed=99, missing_rate=missing_rate)
     outs = []
     for batch in (1, 16, 64, 256):
         dev = capi.Device(0)
         dev.load_bed(bed, 3000)
         dev.set_option("batch", batch)
+        dev.set_option("gram", 0)
         ch = capi.Chain(dev, y, seed=5)
         for _ in range(3):
             ch.iterate()
@@ -175,6 +179,37 @@ def test_batch_width_does_not_change_the_chain():
             assert np.array_equal(a, b)
         assert np.array_equal(o[1], outs[0][1])
         assert o[2]["sigmaE"] == outs[0][2]["sigmaE"] and np.array_equal(o[2]["rng_x"], outs[0][2]["rng_x"])
+
+
+@pytest.mark.parametrize("batch", [2, 9, 64, 256])
+def test_gram_extension_matches_oracle_and_plain_path(oracle, batch):
+    """Past the first predicted event a launch continues with dots corrected by
+    dbeta * x_j'x_pivot (integer Gram term): same chain as the plain path up to
+    fp rounding -- components exact, beta / residual to 1e-9 -- and as the oracle."""
+    M, N = 600, 2600
+    bed, y = make_case(M, N, seed=123, missing_rate=0.0)
+    ref = orc.Chain(oracle, bed, N, y, seed=4)
+    devs = []
+    for gram in (1, 0):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("batch", batch)
+        dev.set_option("gram", gram)
+        devs.append((dev, capi.Chain(dev, y, seed=4)))
+    fewer = False
+    for it in range(6):
+        ref.iterate()
+        for dev, ch in devs:
+            ch.iterate()
+        (bg, cg, ag), (bp, cp, ap) = devs[0][0].get_beta(), devs[1][0].get_beta()
+        assert np.array_equal(cg, cp) and np.array_equal(cg, ref.arr("components")), "it %d" % it
+        assert close(bg, bp) and close(bg, ref.arr("beta")) and close(ag, ref.arr("acum"))
+        assert close(devs[0][0].get_residual(), ref.arr("eps"))
+        sg, sp = devs[0][1].state(), devs[1][1].state()
+        assert close(sg["sigmaE"], ref.sigmaE) and np.array_equal(sg["rng_x"], sp["rng_x"]) and sg["rng_idx"] == sp["rng_idx"]
+        fewer = fewer or devs[0][0].sweep_stats()["launches"] < devs[1][0].sweep_stats()["launches"]
+    if batch >= 9:
+        assert fewer, "the extension never saved a launch: it is not being exercised"
 
 
 @pytest.mark.parametrize("with_comm", [False, True])
@@ -345,8 +380,9 @@ def test_full_size_properties_c2():
         back = dev.get_residual()
         assert np.max(np.abs(back - (ys - st["mu"]))) < 1e-8
         dev.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
-    assert res[0][3]["sigmaE"] == res[1][3]["sigmaE"]
+    # different batch widths cut the Gram-corrected extensions differently: equal up to fp rounding
+    assert np.array_equal(res[0][1], res[1][1]) and close(res[0][0], res[1][0]) and close(res[0][2], res[1][2])
+    assert close(res[0][3]["sigmaE"], res[1][3]["sigmaE"])
 
 
 # ---------------------------------------------------------------------------
