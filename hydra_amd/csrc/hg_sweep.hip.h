@@ -578,12 +578,19 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     if ((nb == 0 && !pend) || d.error) return; // whole grid agrees: nothing left to do
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t c0 = blockIdx.y * CPG;
+    // 1-D grid of slices_max * groups_max workgroups; the ACTIVE ones are the first S * nactive
+    // in dispatch order (idle ones behind them leave at once and delay nobody)
+    const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
+    // slices actually used: keep the active workgroups co-resident (3 per CU at this register
+    // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
+    constexpr uint32_t RES = (CPG >= 16) ? 512u : 768u; // co-resident workgroups at this instantiation's register budget
+    const uint32_t S = (RES / nactive) < p.slices_max ? ((RES / nactive) ? RES / nactive : 1u) : p.slices_max;
+    if (blockIdx.x >= S * nactive) return;
+    const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
+    const uint32_t c0 = group * CPG;
     const uint32_t c1 = (c0 + CPG < nb) ? c0 + CPG : nb;
     const uint32_t ncol = (c1 > c0) ? c1 - c0 : 0u;
-    const bool first_group = blockIdx.y == 0;
-    if (ncol == 0 && !first_group) return; // column group beyond this launch's batch: not part of the ticket
-    const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
+    const bool first_group = group == 0;
     const double* eps_in = d.cur ? p.eps1 : p.eps0;
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
     if (!p.sums_out) stage_rng(p, sh, tid);
     const PivotScan scan = p.sums_out ? PivotScan{0u, 0u} : load_pivot_scan(p, d, tid);
-    if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.dbg[0] = wall_clock64();
+    if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
     unsigned long long t_loop = 0ull;
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const uint8_t* pendp1 = p.bed + (size_t)(pend1 ? d.pend_marker[1] : 0) * p.stride + (lane << 2);
 
     {
-        for (uint32_t tg = blockIdx.x; tg < ntg; tg += gridDim.x) {
+        for (uint32_t tg = slice; tg < ntg; tg += S) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             double e[IPT];
             load_eps16(eps_in, tile, lane, e);
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + (NROW * c0 + t), v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + (NROW * c0 + t), v, HG_RLX_AGENT);
         }
         if (first_group && tid == BLOCK - 1) {
             const uint32_t t = NROW * CPG;
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)blockIdx.x * ROWS_CAP + NROW * MAX_BATCH, v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + NROW * MAX_BATCH, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        sh.flags[F_LAST] = (t == gridDim.x * nactive - 1u) ? 1u : 0u;
+        sh.flags[F_LAST] = (t == S * nactive - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (!sh.flags[F_LAST]) return;
@@ -736,7 +743,6 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     // loads in flight); row total = (slices 0..31) + (slices 32..63).
     {
         const uint32_t nrows = NROW * nb + 1;
-        const uint32_t S = gridDim.x;
         const uint32_t half = tid >> 7, rl = tid & 127u;
         for (uint32_t rr0 = 0; rr0 < nrows; rr0 += 128) {
             const uint32_t rr = rr0 + rl;

@@ -1054,7 +1054,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
 
     const uint32_t ntg = h->n_pad / BLOCK_IND;
     const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
-    const dim3 grid(S, ngroups);
+    p.slices_max = S;
+    const dim3 grid(S * ngroups);
     uint64_t total_launches = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     double avg_accept = std::max(1.0, (double)batch * 0.5);
