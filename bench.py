@@ -306,7 +306,7 @@ def main():
                        "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": launches / K, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (128 if (hi - lo) >= 200000 or world > 1 else 64), world),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (256 if (hi - lo) >= 200000 or world > 1 else 128), world),
                          "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
                          "sweep_ms_per_iter": sweep_ms / K},
