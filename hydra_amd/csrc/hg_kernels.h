@@ -127,6 +127,7 @@ struct SweepParams {
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)
     uint32_t slices_max;     // most tile-group slices a launch may use (<= S_CAP)
+    uint32_t ext_limit;      // longest Gram-corrected extension past the pivot
     // multi-GPU: when non-null the kernel stops after the local reduction and
     // leaves sums[NROW*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;

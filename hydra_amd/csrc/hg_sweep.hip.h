@@ -46,6 +46,7 @@ struct SweepShared {
     uint32_t* flags;   // see F_* below
     uint32_t* red_u;   // 4 words: block minimum scratch
     uint8_t* ada;
+    unsigned char* estage; // BLOCK_WAVES x 8 KiB: eps tile of each wave, filled by LDS-DMA (overlays the tail arrays)
     double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
     double* red;       // 128 doubles: exchange buffer of the tail reduction
     double* ev;        // 8 doubles: event hand-off between the walk and the rest of the workgroup
@@ -54,17 +55,31 @@ struct SweepShared {
 };
 enum { F_LAST = 0, F_POS = 1, F_P2PTMO = 2, F_NACC = 3, F_STOP = 4, F_FPOS = 5, F_FMARK = 6, F_ERR = 7 };
 
-__host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K)
+constexpr size_t EPS_STAGE_BYTES = (size_t)BLOCK_WAVES * TILE * sizeof(double); // one wave tile of eps per wave (LDS-DMA target)
+
+__host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K)
 {
     size_t n = 0;
-    n += MT_BUF * 4;
-    n += 2 * 130 * 8;
-    n += (size_t)BLOCK_WAVES * (NROW * cpg + 1) * 8;
-    n += (size_t)(NROW * bcap + 1) * 8;
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)4 * bcap * 8;
-    n += (size_t)2 * bcap * 4 + 32 + 16 + ((bcap + 15) & ~15u);
-    n += (size_t)4 * HT_LDS * 8 + 128 * 8 + 8 * 8;
+    n += (size_t)(NROW * bcap + 1) * 8;                                                       // tot
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)4 * bcap * 8;        // thr, muk, logl, bold/mave/mstd/dp
+    n += (size_t)2 * bcap * 4 + ((bcap + 15) & ~15u);                                         // marker, grp, ada
     return (n + 15) & ~(size_t)15;
+}
+
+__host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg)
+{
+    size_t n = 0;
+    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 8 * 8 + 32 + 16;
+    n += (size_t)BLOCK_WAVES * (NROW * cpg + 1) * 8;
+    return (n + 15) & ~(size_t)15;
+}
+
+// fixed region (staged generator / tables / small scratch, live for the whole launch), then a
+// UNION: the streaming loop's eps staging tiles and the last arriver's per-batch arrays
+__host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K)
+{
+    const size_t tail = sweep_lds_tail_bytes(bcap, K);
+    return sweep_lds_fixed_bytes(cpg) + (tail > EPS_STAGE_BYTES ? tail : EPS_STAGE_BYTES);
 }
 
 __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint32_t bcap, uint32_t cpg, int K)
@@ -74,8 +89,15 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
+    sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
+    sh.red = reinterpret_cast<double*>(q); q += 128 * 8;
+    sh.ev = reinterpret_cast<double*>(q); q += 8 * 8;
+    sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
+    sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
     sh.wstride = NROW * cpg + 1;
-    sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
+    sh.wpart = reinterpret_cast<double*>(q);
+    q = base + sweep_lds_fixed_bytes(cpg);
+    sh.estage = q; // union starts here
     sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NROW * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
@@ -86,12 +108,7 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.dp = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
     sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
-    sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
-    sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
-    sh.ada = q; q += (bcap + 15) & ~15u;
-    sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
-    sh.red = reinterpret_cast<double*>(q); q += 128 * 8;
-    sh.ev = reinterpret_cast<double*>(q);
+    sh.ada = q;
     sh.bcap = bcap;
     return sh;
 }
@@ -453,6 +470,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             if (!p.gram || pivot_miss != 0u) want2 = want1;
             else if (e == 0xffffffffu) want2 = cap;
             else want2 = e_miss ? e : e + 1u; // a column with missing calls stays out of the extension
+            if (want2 > want1 + p.ext_limit) want2 = want1 + p.ext_limit;
             if (want2 > cap) want2 = cap;
             if (want2 < want1) want2 = want1;
         }
@@ -566,7 +584,7 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDe
 // columns in registers across all its tiles; one wave/block reduction per
 // launch, then per-slice partial rows for the last arriver.
 template <int CPG>
-__global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
+__global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
     const SweepDesc d = *p.desc;
@@ -630,25 +648,60 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
     const uint8_t* pendp1 = p.bed + (size_t)(pend1 ? d.pend_marker[1] : 0) * p.stride + (lane << 2);
 
     {
-        for (uint32_t tg = slice; tg < ntg; tg += S) {
+        // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces --
+        // exactly the permuted eps layout) one tile ahead of the arithmetic; column dwords of the
+        // next tile are prefetched into registers.
+        unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
+        auto dma_eps = [&](uint32_t tile) {
+            const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
+                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
+        };
+        uint32_t w[CPG], wn[CPG], wpiv = 0, wpivn = 0, wp0 = 0, wp0n = 0, wp1 = 0, wp1n = 0;
+        uint32_t tg = slice;
+        if (tg < ntg) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
-            double e[IPT];
-            load_eps16(eps_in, tile, lane, e);
-            uint32_t w[CPG];
+            dma_eps(tile);
 #pragma unroll
             for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8));
+            if (any_gram) wpiv = *reinterpret_cast<const uint32_t*>(pivp + ((size_t)tile << 8));
+            if (pend) wp0 = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tile << 8));
+            if (pend1) wp1 = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tile << 8));
+        }
+        for (; tg < ntg; tg += S) {
+            const uint32_t tile = tg * BLOCK_WAVES + wave;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this tile's DMA (and column dwords) have landed
+            double e[IPT];
+            {
+                const double2* lp = reinterpret_cast<const double2*>(est) + lane;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double2 v = lp[k * 64];
+                    e[2 * k] = v.x;
+                    e[2 * k + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // eps is in registers: the staging tile may be overwritten
+            const uint32_t tgn = tg + S;
+            if (tgn < ntg) {
+                const uint32_t tilen = tgn * BLOCK_WAVES + wave;
+                dma_eps(tilen);
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) wn[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tilen << 8));
+                if (any_gram) wpivn = *reinterpret_cast<const uint32_t*>(pivp + ((size_t)tilen << 8));
+                if (pend) wp0n = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tilen << 8));
+                if (pend1) wp1n = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tilen << 8));
+            }
             uint32_t gwp = 0;
             if (any_gram) {
                 uint32_t nmp;
-                code_weights(*reinterpret_cast<const uint32_t*>(pivp + ((size_t)tile << 8)), gwp, nmp);
+                code_weights(wpiv, gwp, nmp);
             }
             if (pend) { // the previous launch's event(s), in order
-                const uint32_t wp0 = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tile << 8));
                 apply_update16(wp0, d.pv[0][0], d.pv[0][1], d.pv[0][2], e);
-                if (pend1) {
-                    const uint32_t wp1 = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tile << 8));
-                    apply_update16(wp1, d.pv[1][0], d.pv[1][1], d.pv[1][2], e);
-                }
+                if (pend1) apply_update16(wp1, d.pv[1][0], d.pv[1][1], d.pv[1][2], e);
                 if (first_group) store_eps16(eps_out, tile, lane, e);
             }
             if (first_group) {
@@ -680,7 +733,15 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_batch(SweepParams p)
                 }
                 if (cgram[c]) ag[c] += gram16(gw[c], gwp);
             }
+            if (tgn < ntg) {
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) w[c] = wn[c];
+                wpiv = wpivn;
+                wp0 = wp0n;
+                wp1 = wp1n;
+            }
         }
+        __syncthreads(); // every wave is done with its staging tile: the union region may be reused
         t_loop = p.dbg ? wall_clock64() : 0ull;
         // one cross-lane reduction per launch
 #pragma unroll

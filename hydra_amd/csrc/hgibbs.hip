@@ -112,6 +112,7 @@ struct hgibbs_ctx {
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
+    uint32_t ext_limit = 256;
     bool gram = true; // Gram-corrected continuation past the first predicted event
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
@@ -906,6 +907,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "ext_limit")) {
+        if (value < 0 || value > MAX_BATCH) return fail("ext_limit must be in [0,%d]", MAX_BATCH);
+        h->ext_limit = (uint32_t)value;
     } else if (!std::strcmp(name, "gram")) {
         h->gram = value != 0;
     } else if (!std::strcmp(name, "p2p")) {
@@ -1039,6 +1043,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
+    p.ext_limit = h->ext_limit;
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;

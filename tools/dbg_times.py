@@ -9,9 +9,11 @@ cfg, batch, cpg = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 N, M, G, mS = bench.CONFIGS[cfg]
 if len(sys.argv) > 4: M = int(sys.argv[4])
 slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ext = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 dev = capi.Device(0)
 dev.set_option("batch", batch); dev.set_option("cols_per_group", cpg); dev.set_option("debug_timing", 1)
 if slices: dev.set_option("slices", slices)
+if ext >= 0: dev.set_option("ext_limit", ext)
 dev.synth_bed(N, M, seed=42)
 y = bench.make_phenotype_on_device(dev, N, M, (0, N), seed=43)
 ch = capi.Chain(dev, y, mS=np.array(mS))
