@@ -16,7 +16,8 @@ ABI_SYMBOLS = [
     "hgibbs_last_error", "hgibbs_version", "hgibbs_create", "hgibbs_destroy", "hgibbs_comm_unique_id",
     "hgibbs_comm_init", "hgibbs_comm_init_external", "hgibbs_p2p_export", "hgibbs_p2p_import", "hgibbs_load_bed", "hgibbs_synth_bed", "hgibbs_dims", "hgibbs_get_bed",
     "hgibbs_marker_stats", "hgibbs_set_residual", "hgibbs_get_residual", "hgibbs_reduce_eps", "hgibbs_add_scalar",
-    "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
+    "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_covariates", "hgibbs_cov_dot", "hgibbs_cov_update",
+    "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
     "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
@@ -76,6 +77,11 @@ def lib():
     L.hgibbs_add_scalar.argtypes = [vp, C.c_double]
     L.hgibbs_update_marker.argtypes = [vp, C.c_uint32, C.c_double]
     L.hgibbs_dot_marker.argtypes = [vp, C.c_uint32, dp]
+    L.hgibbs_set_covariates.argtypes = [vp, dp, C.c_int]
+    L.hgibbs_cov_dot.argtypes = [vp, C.c_int, C.c_double, dp]
+    L.hgibbs_cov_update.argtypes = [vp, C.c_int, C.c_double]
+    L.hydra_chain_set_covariates.argtypes = [vp, dp, C.c_int]
+    L.hydra_chain_gamma.argtypes = [vp, dp, ip]
     L.hgibbs_set_model.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
     L.hgibbs_set_beta.argtypes = [vp, dp]
     L.hgibbs_get_beta.argtypes = [vp, dp, ip, dp]
@@ -306,6 +312,17 @@ class Chain:
                 self.L.hydra_chain_destroy(self.h)
         except Exception:
             pass
+
+    def set_covariates(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.shape[0] == self.dev.n_global
+        self.C = X.shape[1]
+        check(self.L.hydra_chain_set_covariates(self.h, _dp(X), self.C))
+
+    def gamma(self):
+        g, xi = np.zeros(self.C), np.zeros(self.C, dtype=np.int32)
+        check(self.L.hydra_chain_gamma(self.h, _dp(g), _ip(xi)))
+        return g, xi
 
     def iterate(self):
         check(self.L.hydra_chain_iterate(self.h))

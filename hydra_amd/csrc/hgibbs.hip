@@ -77,6 +77,10 @@ struct hgibbs_ctx {
     unsigned long long* counts = nullptr; // 3*M: n1, n2, nmiss (global after all-reduce)
     bool have_stats = false;
 
+    // covariates: C columns of n_pad doubles in the permuted eps layout
+    double* covX = nullptr;
+    int C = 0;
+
     // model / effects
     int G = 0, K = 0;
     int32_t* groups = nullptr;
@@ -414,6 +418,49 @@ __global__ __launch_bounds__(BLOCK) void k_dot_one(const uint8_t* __restrict__ b
     }
 }
 
+// covariate column (row-major host matrix) -> permuted device column
+__global__ void k_set_cov(double* dst, const double* __restrict__ X, uint32_t n_local, uint32_t n_pad, int C, int c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    dst[eps_pos(i)] = (i < n_local) ? X[(size_t)i * C + c] : 0.0;
+}
+
+// per-block partial of sum_k x_k * (eps_k + g * x_k)   (src/BayesRRm.cpp:2666-2668)
+__global__ __launch_bounds__(BLOCK) void k_cov_dot(const double* __restrict__ x, const double* __restrict__ eps, double g, double* partial)
+{
+    __shared__ double sh[BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT], xv[IPT];
+    load_eps16(eps, tile, lane, e);
+    load_eps16(x, tile, lane, xv);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) s += xv[i] * (e[i] + g * xv[i]);
+    s = wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) t += sh[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// eps_k = eps_k + d * x_k   (src/BayesRRm.cpp:2673-2676)
+__global__ __launch_bounds__(BLOCK) void k_cov_update(const double* __restrict__ x, double* eps, double dgam)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT], xv[IPT];
+    load_eps16(eps, tile, lane, e);
+    load_eps16(x, tile, lane, xv);
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) e[i] = e[i] + dgam * xv[i];
+    store_eps16(eps, tile, lane, e);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_update_one(const uint8_t* __restrict__ bed, uint64_t stride, uint32_t marker,
                                                       double* eps, double v0, double v1, double v2)
 {
@@ -481,7 +528,7 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -834,6 +881,53 @@ int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num)
     dp -= (h->scratch_host[4] * syt);
     dp *= h->scratch_host[5];
     *num = dp;
+    return 0;
+}
+
+int hgibbs_set_covariates(hgibbs_t h, const double* X_host, int C)
+{
+    if (!h || !h->bed) return fail("hgibbs_set_covariates: load genotypes first");
+    if (C < 0 || (C > 0 && !X_host)) return fail("hgibbs_set_covariates: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->covX) HIP_TRY(hipFree(h->covX));
+    h->covX = nullptr;
+    h->C = C;
+    if (C == 0) return 0;
+    HIP_TRY(hipMalloc(&h->covX, (size_t)C * h->n_pad * sizeof(double)));
+    double* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)h->n_local * C * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(tmp, X_host, (size_t)h->n_local * C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int c = 0; c < C; ++c)
+        k_set_cov<<<(h->n_pad + 255) / 256, 256, 0, h->stream>>>(h->covX + (size_t)c * h->n_pad, tmp, h->n_local, h->n_pad, C, c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(tmp));
+    return 0;
+}
+
+int hgibbs_cov_dot(hgibbs_t h, int c, double gamma_old, double* num_f)
+{
+    if (!h || !h->covX || !num_f) return fail("hgibbs_cov_dot: no covariates set");
+    if (c < 0 || c >= h->C) return fail("hgibbs_cov_dot: covariate %d outside [0,%d)", c, h->C);
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblk = h->n_pad / BLOCK_IND;
+    k_cov_dot<<<nblk, BLOCK, 0, h->stream>>>(h->covX + (size_t)c * h->n_pad, h->eps[h->eps_cur], gamma_old, h->scratch);
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 1, h->sums);
+    HIP_TRY(hipGetLastError());
+    if (bulk_allreduce(h, h->sums, 1, 0)) return 1;
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *num_f = h->scratch_host[0];
+    return 0;
+}
+
+int hgibbs_cov_update(hgibbs_t h, int c, double dgamma)
+{
+    if (!h || !h->covX) return fail("hgibbs_cov_update: no covariates set");
+    if (c < 0 || c >= h->C) return fail("hgibbs_cov_update: covariate %d outside [0,%d)", c, h->C);
+    HIP_TRY(hipSetDevice(h->device));
+    k_cov_update<<<h->n_pad / BLOCK_IND, BLOCK, 0, h->stream>>>(h->covX + (size_t)c * h->n_pad, h->eps[h->eps_cur], dgamma);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -40,6 +40,11 @@ struct hydra_chain {
     double sigmaE = 0.0, mu = 0.0;
     hgibbs_rng_state rng{};
     uint64_t last_nnz = 0;
+    // fixed effects (:1113-1114, :1552-1553)
+    int C = 0;
+    std::vector<double> gamma;
+    std::vector<unsigned int> xI;
+    uint32_t row_begin = 0, n_local = 0;
     uint32_t iteration = 0;
 };
 
@@ -65,6 +70,8 @@ int hydra_chain_create(hgibbs_t dev, const hydra_model_desc* model, const double
     c->dev = dev;
     c->N = n_global;
     c->M = M;
+    c->row_begin = row_begin;
+    c->n_local = n_local;
     c->G = model->G;
     c->K = model->K;
     c->shuffle = model->shuffle;
@@ -217,6 +224,24 @@ int hydra_chain_iterate(hydra_chain_t c)
         for (int k = 0; k < K; ++k) c->estPi[g * K + k] = pi[k];
     }
 
+    // :2646-2681 fixed effects: one conditional normal per covariate, shuffled order
+    if (c->C > 0) {
+        hg::MtUrbg u{&gen};
+        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        const double sigmaF = 1.0; // s02F, src/BayesRRm.h:34 (sigmaF = s02F, :2680)
+        const double sigE_sigF = c->sigmaE / sigmaF;
+        const double dNm1 = (double)(c->N - 1);
+        for (int i = 0; i < c->C; ++i) {
+            const int col = (int)c->xI[i];
+            const double gamma_old = c->gamma[col];
+            double num_f = 0.0;
+            if (hgibbs_cov_dot(c->dev, col, gamma_old, &num_f)) return 1;
+            const double denom_f = dNm1 + sigE_sigF;
+            c->gamma[col] = hg::norm_rng(gen, num_f / denom_f, c->sigmaE / denom_f);
+            if (hgibbs_cov_update(c->dev, col, gamma_old - c->gamma[col])) return 1;
+        }
+    }
+
     // :2685-2690
     double e_sqn = 0.0;
     if (hgibbs_reduce_eps(c->dev, nullptr, &e_sqn)) return 1;
@@ -237,6 +262,28 @@ int hydra_chain_state(hydra_chain_t c, double* sigmaE, double* mu, double* sigma
     if (m0) std::copy(c->m0.begin(), c->m0.end(), m0);
     if (cass) std::copy(c->cass.begin(), c->cass.end(), cass);
     if (rng) *rng = c->rng;
+    return 0;
+}
+
+int hydra_chain_set_covariates(hydra_chain_t c, const double* X_host, int C)
+{
+    if (!c) return cfail("hydra_chain_set_covariates: null chain");
+    if (C < 0 || (C > 0 && !X_host)) return cfail("hydra_chain_set_covariates: bad argument");
+    if (c->iteration != 0) return cfail("hydra_chain_set_covariates: call before the first iteration");
+    c->C = C;
+    c->gamma.assign(C, 0.0);
+    c->xI.resize(C);
+    for (int i = 0; i < C; ++i) c->xI[i] = (unsigned)i;
+    return hgibbs_set_covariates(c->dev, C ? X_host + (size_t)c->row_begin * C : nullptr, C);
+}
+
+int hydra_chain_gamma(hydra_chain_t c, double* gamma_out, int32_t* xI_out)
+{
+    if (!c) return cfail("hydra_chain_gamma: null chain");
+    for (int i = 0; i < c->C; ++i) {
+        if (gamma_out) gamma_out[i] = c->gamma[i];
+        if (xI_out) xI_out[i] = (int32_t)c->xI[i];
+    }
     return 0;
 }
 

@@ -9,7 +9,7 @@
 // .eps.<rank> .mrk.<rank> .xbet .xcpn (:2802-2838).
 //
 // Not reproduced (out of scope for the hot path): sparse
-// file formats, --restart, covariates, bayesFH/bayesW, marker-sharded MPI.
+// file formats, --restart, bayesFH/bayesW, marker-sharded MPI.
 // Multi-GPU: one process per GPU (RANK/WORLD_SIZE/LOCAL_RANK in the
 // environment, as torchrun/mpirun export them); individuals are sharded and the
 // ncclUniqueId travels through a file in --mcmc-out-dir.
@@ -36,7 +36,8 @@ namespace {
 
 struct Options { // src/options.hpp:20-138 (subset that reaches bayesMPI)
     std::string bayesType, analysisType = "Bayes";
-    std::string bedFile, phenotypeFile, mcmcOutDir, mcmcOutNam, groupIndexFile, groupMixtureFile;
+    std::string bedFile, phenotypeFile, mcmcOutDir, mcmcOutNam, groupIndexFile, groupMixtureFile, covariatesFile;
+    bool covariates = false;
     unsigned chainLength = 10000, burnin = 5000, thin = 5, save = 10;
     unsigned seed = 0;
     bool seedGiven = false;
@@ -104,7 +105,10 @@ Options parse(int argc, const char* argv[])
         else if (a == "--groupMixtureFile") o.groupMixtureFile = need(i);
         else if (a == "--batch") o.batch = std::atoi(need(i));
         else if (a == "--cols-per-group") o.cpg = std::atoi(need(i));
-        else if (a == "--sparse-dir" || a == "--sparse-basename" || a == "--restart" || a == "--covariates" ||
+        else if (a == "--covariates") {
+            o.covariates = true;
+            o.covariatesFile = need(i);
+        } else if (a == "--sparse-dir" || a == "--sparse-basename" || a == "--restart" ||
                  a == "--bed-to-sparse" || a == "--sparse-sync" || a == "--bed-sync" || a == "--failure" || a == "--quad_points")
             fatal("FATAL  : option " + a + " belongs to a part of hydra this build does not reproduce (SURVEY.md section 2)");
         else
@@ -169,6 +173,40 @@ void read_phen(const std::string& path, const std::vector<std::string>& fam_ids,
         ++lineno;
     }
     if (lineno != fam_ids.size()) fatal("FATAL  : phenotype file covers " + std::to_string(lineno) + " of " + std::to_string(fam_ids.size()) + " individuals");
+}
+
+// Data::readPhenCovFiles, src/data.cpp:1615-1673: .phen and .cov are read line by line in
+// lockstep (no .fam lookup); an individual is dropped if its phenotype or any covariate is NA.
+void read_phen_cov(const std::string& phen, const std::string& cov, size_t numInds, std::vector<double>& y,
+                   std::vector<uint8_t>& keep, std::vector<double>& X, int& C)
+{
+    std::ifstream inp(phen), inc(cov);
+    if (!inp) fatal("Error: can not open the phenotype file [" + phen + "] to read.");
+    if (!inc) fatal("Error: can not open the covariates file [" + cov + "] to read.");
+    keep.assign(numInds, 1);
+    y.clear();
+    X.clear();
+    std::string lp, lc;
+    size_t line = 0;
+    while (std::getline(inp, lp)) {
+        if (!std::getline(inc, lc)) fatal("FATAL  : covariates file is shorter than the phenotype file");
+        if (line >= numInds) break;
+        std::vector<std::string> cp = tokens(lp, " \t"), cc = tokens(lc, " \t");
+        if (cp.size() < 3) continue;
+        bool naC = false;
+        for (size_t i = 2; i < cc.size(); ++i)
+            if (cc[i] == "NA") naC = true;
+        if (cp[2] != "NA" && !naC) {
+            y.push_back(std::atof(cp[2].c_str()));
+            for (size_t i = 2; i < cc.size(); ++i) X.push_back(std::stod(cc[i]));
+        } else {
+            keep[line] = 0;
+        }
+        ++line;
+    }
+    if (line != numInds) fatal("FATAL  : phenotype/covariates files cover " + std::to_string(line) + " of " + std::to_string(numInds) + " individuals");
+    C = y.empty() ? 0 : (int)(X.size() / y.size());
+    std::printf("numFixedEffect = %d\n", C);
 }
 
 std::vector<int32_t> read_groups(const std::string& path) // data.cpp:1940-1958
@@ -255,7 +293,10 @@ int main(int argc, const char* argv[])
     const size_t numSnps = count_bim(opt.bedFile + ".bim");
     std::vector<double> y;
     std::vector<uint8_t> keep;
-    read_phen(opt.phenotypeFile, fam_ids, y, keep);
+    std::vector<double> covX;
+    int C = 0;
+    if (opt.covariates) read_phen_cov(opt.phenotypeFile, opt.covariatesFile, numInds, y, keep, covX, C); // main.cpp:80-83
+    else read_phen(opt.phenotypeFile, fam_ids, y, keep);
     const unsigned numNAs = (unsigned)(numInds - y.size());
 
     if (opt.numberIndividuals == 0) fatal("FATAL  : opt.numberIndividuals is zero! Set it via --number-individuals in call.");
@@ -415,6 +456,10 @@ int main(int argc, const char* argv[])
     md.mS = mS_flat.data();
     hydra_chain_t chain = nullptr;
     hg_check(hydra_chain_create(dev, &md, y.data(), &chain), "hydra_chain_create");
+    if (opt.covariates) {
+        if (rank == 0) std::printf("INFO   : using covariate file: %s\n", opt.covariatesFile.c_str());
+        hg_check(hydra_chain_set_covariates(chain, covX.data(), C), "hydra_chain_set_covariates");
+    }
 
     // ---- outputs (rank 0 writes the shared files) ----------------------------
     FILE *outf = nullptr, *betf = nullptr, *cpnf = nullptr, *acuf = nullptr, *xbetf = nullptr, *xcpnf = nullptr;
@@ -435,6 +480,10 @@ int main(int argc, const char* argv[])
     FILE* musf = open_trunc(base + ".mus." + std::to_string(rank));
     FILE* epsf = open_trunc(base + ".eps." + std::to_string(rank));
     FILE* mrkf = open_trunc(base + ".mrk." + std::to_string(rank));
+    FILE* gamf = open_trunc(base + ".gam." + std::to_string(rank));
+    FILE* xivf = open_trunc(base + ".xiv." + std::to_string(rank));
+    std::vector<double> gamma(C);
+    std::vector<int32_t> xiv(C);
 
     std::vector<double> beta(Mtot), acum(Mtot), eps(hi - lo);
     std::vector<int32_t> comp(Mtot);
@@ -492,6 +541,16 @@ int main(int argc, const char* argv[])
             pwrite_at(mrkf, 0, &iteration, sizeof(unsigned));
             pwrite_at(mrkf, sizeof(unsigned), &Mtot, sizeof(unsigned));
             pwrite_at(mrkf, 2 * sizeof(unsigned), hydra_chain_order(chain), (size_t)Mtot * sizeof(int));
+            if (opt.covariates) { // :2810-2832
+                const unsigned glen = (unsigned)C;
+                hydra_chain_gamma(chain, gamma.data(), xiv.data());
+                for (FILE* f : {gamf, xivf}) {
+                    pwrite_at(f, 0, &iteration, sizeof(unsigned));
+                    pwrite_at(f, sizeof(unsigned), &glen, sizeof(unsigned));
+                }
+                pwrite_at(gamf, 2 * sizeof(unsigned), gamma.data(), (size_t)C * sizeof(double));
+                pwrite_at(xivf, 2 * sizeof(unsigned), xiv.data(), (size_t)C * sizeof(int));
+            }
             if (rank == 0) {
                 hg_check(hgibbs_get_beta(dev, beta.data(), comp.data(), nullptr), "hgibbs_get_beta");
                 pwrite_at(xbetf, sizeof(unsigned), &iteration, sizeof(unsigned));
@@ -504,7 +563,7 @@ int main(int argc, const char* argv[])
     if (rank == 0)
         std::printf("INFO   : rank %4d, time to process the data: %.3f sec, with %.3f (%.3f, %.3f) = %4.1f%% spent on allred (%d, %d)\n", rank,
                     now_s() - t_all, 0.0, 0.0, 0.0, 0.0, 0, 0);
-    for (FILE* f : {outf, betf, cpnf, acuf, xbetf, xcpnf, musf, epsf, mrkf})
+    for (FILE* f : {outf, betf, cpnf, acuf, xbetf, xcpnf, musf, epsf, mrkf, gamf, xivf})
         if (f) std::fclose(f);
     hydra_chain_destroy(chain);
     hgibbs_destroy(dev);

@@ -111,6 +111,15 @@ int hgibbs_update_marker(hgibbs_t h, uint32_t marker, double dbeta);
  * summed over ranks (src/BayesRRm.cpp:316-342). */
 int hgibbs_dot_marker(hgibbs_t h, uint32_t marker, double* num);
 
+/* ---- fixed-effect covariates (src/BayesRRm.cpp:2648-2681) ---------------- */
+/* X_host: this rank's n_local x C covariate values, row-major (what data.X holds
+ * for these individuals; hydra expects them standardised: x'x = N-1). */
+int hgibbs_set_covariates(hgibbs_t h, const double* X_host, int C);
+/* num_f = sum_k X(k,c) * (eps_k + gamma_old * X(k,c)) over all ranks (:2666-2668) */
+int hgibbs_cov_dot(hgibbs_t h, int c, double gamma_old, double* num_f);
+/* eps_k = eps_k + dgamma * X(k,c), dgamma = gamma_old - gamma_new (:2673-2676) */
+int hgibbs_cov_update(hgibbs_t h, int c, double dgamma);
+
 /* ---- model (src/BayesRRm.cpp:1037-1110) --------------------------------- */
 /* groups_host[M] in [0,G); cVa/cVaI are G*K row-major with column 0 == 0. */
 int hgibbs_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const double* cVa_host,
@@ -163,7 +172,11 @@ typedef struct {
  * NA rows removed); the chain centres/scales it (src/BayesRRm.cpp:1564-1579). */
 int hydra_chain_create(hgibbs_t dev, const hydra_model_desc* model, const double* y_host, hydra_chain_t* out);
 int hydra_chain_destroy(hydra_chain_t c);
-/* one Gibbs iteration: mu, shuffle, sweep, sigmaG/pi per group, sigmaE */
+/* optional fixed effects (--covariates): X_host = n_global x C row-major, same
+ * individuals and order as y_host; call once before the first iteration */
+int hydra_chain_set_covariates(hydra_chain_t c, const double* X_host, int C);
+int hydra_chain_gamma(hydra_chain_t c, double* gamma_out /* C */, int32_t* xI_out /* C, may be NULL */);
+/* one Gibbs iteration: mu, shuffle, sweep, sigmaG/pi per group, covariates, sigmaE */
 int hydra_chain_iterate(hydra_chain_t c);
 /* hyper-parameters after the last iteration; any pointer may be NULL */
 int hydra_chain_state(hydra_chain_t c, double* sigmaE, double* mu, double* sigmaG /*G*/, double* estPi /*G*K*/,

@@ -463,6 +463,11 @@ struct orc_chain {
     long last_nnz;
     orc_mt rng;
     uint32_t iteration;
+    /* fixed effects (src/BayesRRm.cpp:1113-1114,1552-1553,2646-2681) */
+    int C;
+    std::vector<double> X; /* N x C row-major */
+    std::vector<double> gamma;
+    std::vector<unsigned int> xI;
 };
 
 static const double V0E = 0.0001, S02E = 0.0001, V0G = 0.0001, S02G = 0.0001; /* src/BayesRRm.h:30-33 */
@@ -476,7 +481,7 @@ orc_chain* orc_chain_create(const uint8_t* bed, uint64_t stride, uint32_t N, uin
 {
     orc_chain* c = new orc_chain();
     c->N = N; c->M = M; c->stride = stride; c->bed = bed; c->G = G; c->K = K;
-    c->shuffle = shuffle; c->iteration = 0; c->last_nnz = 0;
+    c->shuffle = shuffle; c->iteration = 0; c->last_nnz = 0; c->C = 0;
     c->groups.assign(groups, groups + M);
     const int km1 = K - 1;
 
@@ -592,11 +597,38 @@ void orc_chain_iter_end(orc_chain* c)
         for (int k = 0; k < K; ++k) c->estPi[g * K + k] = pi[k];
     }
 
+    if (c->C > 0) { /* :2646-2681 */
+        MtUrbg u{&c->rng};
+        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        const double sigmaF = 1.0;
+        const double sigE_sigF = c->sigmaE / sigmaF;
+        const double dNm1 = (double)(N - 1);
+        for (int i = 0; i < c->C; ++i) {
+            const unsigned col = c->xI[i];
+            const double gamma_old = c->gamma[col];
+            double num_f = 0.0;
+            for (uint32_t k = 0; k < N; ++k) num_f += c->X[(size_t)k * c->C + col] * (c->eps[k] + gamma_old * c->X[(size_t)k * c->C + col]);
+            const double denom_f = dNm1 + sigE_sigF;
+            c->gamma[col] = orc_norm_rng(&c->rng, num_f / denom_f, c->sigmaE / denom_f);
+            for (uint32_t k = 0; k < N; ++k) c->eps[k] = c->eps[k] + (gamma_old - c->gamma[col]) * c->X[(size_t)k * c->C + col];
+        }
+    }
+
     double e_sqn = 0.0;
     for (uint32_t i = 0; i < N; ++i) e_sqn += c->eps[i] * c->eps[i];
     c->sigmaE = orc_inv_scaled_chisq_rng(&c->rng, V0E + dN, (e_sqn + V0E * S02E) / (V0E + dN));
     c->iteration += 1;
 }
+
+void orc_chain_set_covariates(orc_chain* c, const double* X, int C)
+{
+    c->C = C;
+    c->X.assign(X, X + (size_t)c->N * C);
+    c->gamma.assign(C, 0.0);
+    c->xI.resize(C);
+    for (int i = 0; i < C; ++i) c->xI[i] = (unsigned)i;
+}
+double* orc_chain_gamma(orc_chain* c) { return c->gamma.data(); }
 
 void orc_chain_iterate(orc_chain* c)
 {

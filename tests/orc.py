@@ -48,6 +48,9 @@ def load(name="liboracle.so"):
     for f in ("destroy", "iter_begin", "iter_end", "iterate"):
         getattr(L, "orc_chain_" + f).argtypes = [C.c_void_p]
         getattr(L, "orc_chain_" + f).restype = None
+    L.orc_chain_set_covariates.argtypes = [C.c_void_p, dp, C.c_int]
+    L.orc_chain_gamma.argtypes = [C.c_void_p]
+    L.orc_chain_gamma.restype = dp
     L.orc_chain_sweep.argtypes = [C.c_void_p]
     L.orc_chain_sweep.restype = C.c_long
     for f in ("beta", "acum", "eps", "y", "sigmaG", "estPi", "mave", "mstd", "cVa", "cVaI"):
@@ -150,6 +153,14 @@ class Chain:
     def rng_state(self):
         r = self.L.orc_chain_rng(self.h).contents
         return np.array(r.x, dtype=np.uint32), int(r.idx)
+
+    def set_covariates(self, X):
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.C = self.X.shape[1]
+        self.L.orc_chain_set_covariates(self.h, dptr(self.X), self.C)
+
+    def gamma(self):
+        return np.ctypeslib.as_array(self.L.orc_chain_gamma(self.h), shape=(self.C,)).copy()
 
     def iterate(self):
         self.L.orc_chain_iterate(self.h)

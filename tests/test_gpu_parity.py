@@ -543,3 +543,68 @@ def test_reference_postproc_tools_read_our_files(oracle, tmp_path):
     assert "iteration %d was last logged into epsilon file." % (iters - 1) in eps_txt and "%d individuals were processed." % N in eps_txt
     vals = [float(l.split("=")[1]) for l in eps_txt.splitlines() if "/" in l and "=" in l]
     assert np.allclose(vals, ref.arr("eps"), rtol=0, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------
+# fixed-effect covariates (src/BayesRRm.cpp:2646-2681)
+# ---------------------------------------------------------------------------
+def _cov_case(M, N, C, seed):
+    geno = synth.make_genotypes(M, N, seed=seed, missing_rate=0.01)
+    y, _ = synth.make_phenotype(geno, seed=seed + 1, causal_frac=0.05)
+    rng = np.random.default_rng(seed + 2)
+    X = rng.normal(size=(N, C))
+    X = (X - X.mean(0)) / X.std(0, ddof=0) * np.sqrt((N - 1) / N)  # x'x = N-1, as hydra expects
+    y = y + X @ rng.normal(0, 0.3, C)
+    return geno, y, X
+
+
+def test_covariates_chain_vs_oracle(oracle):
+    M, N, C = 200, 1800, 3
+    geno, y, X = _cov_case(M, N, C, seed=81)
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, seed=11)
+    ref.set_covariates(X)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.Chain(dev, y, seed=11)
+    ch.set_covariates(X)
+    for it in range(6):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, _ = dev.get_beta()
+        g, xi = ch.gamma()
+        assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
+        assert close(g, ref.gamma()) and close(ch.state()["sigmaE"], ref.sigmaE)
+        assert close(dev.get_residual(), ref.arr("eps"))
+    assert np.all(np.abs(g) > 1e-3)  # the fixed effects were actually sampled
+
+
+def test_cli_covariates_with_na(oracle, tmp_path):
+    M, N, C, iters = 80, 500, 2, 5
+    geno, y, X = _cov_case(M, N, C, seed=91)
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, synth.pack_bed_columns(geno), N, y=y, na_rows=[7])
+    with open(prefix + ".cov", "w") as f:
+        for i in range(N):
+            vals = ["NA" if (i == 20 and c == 1) else repr(float(X[i, c])) for c in range(C)]
+            f.write("fam%d ind%d %s\n" % (i, i, " ".join(vals)))
+    r = subprocess.run([EXE, "--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--covariates",
+                        prefix + ".cov", "--mcmc-out-dir", out, "--mcmc-out-name", "r", "--number-individuals", str(N),
+                        "--number-markers", str(M), "--chain-length", str(iters), "--thin", "1", "--save", "2", "--seed", "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    keep = np.ones(N, dtype=bool)
+    keep[[7, 20]] = False
+    ref = orc.Chain(oracle, synth.pack_bed_columns(geno[:, keep]), int(keep.sum()), y[keep], seed=5,
+                    mS=np.array([[0.0, 0.01, 0.001, 0.0001]]))  # hydra's default --S order (options.hpp:108-111)
+    ref.set_covariates(X[keep])
+    _, betas = _read_bet(out + "/r.bet", M, np.float64)
+    gam_it4 = None
+    for it in range(iters):
+        ref.iterate()
+        assert close(betas[it], ref.arr("beta"))
+        if it == 4:
+            gam_it4 = ref.gamma()
+    raw = open(out + "/r.gam.0", "rb").read()
+    it_s, glen = struct.unpack("<II", raw[:8])
+    assert (it_s, glen) == (4, C) and close(np.frombuffer(raw[8:8 + 8 * C], dtype=np.float64), gam_it4)
