@@ -156,32 +156,35 @@ def exchange_self_check(capi, dist, world, rank, local_rank):
     return bool(int(t[0]))
 
 
-def cpu_baseline(dev, y_local_is_full, y, N, M, mS, groups, sample_markers, threads):
-    """The oracle (CPU restatement of hydra's path, OpenMP over individuals as
-    the reference's loops are) timed on a bounded sample: the first
-    `sample_markers` columns of the same genotype matrix, one Gibbs iteration."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
-    lib_name = "liboracle_omp.so"
-    if not os.path.exists(os.path.join(ROOT, "oracle", lib_name)):
-        lib_name = "liboracle.so"
-        threads = 1
-    L = orc.load(lib_name)
-    L.orc_set_threads(threads)
-    L.orc_set_dot_form(2)  # the reference's dense LUT/AVX2 loop structure incl. its bookkeeping passes
+def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
+    """The oracle (CPU restatement of hydra's path: LUT + AVX2 dot, OpenMP over
+    individuals as the reference's loops are, its bookkeeping passes) timed on a
+    bounded sample: the first `sample_markers` columns of the same genotype
+    matrix, one Gibbs iteration after a warm-up one.  Runs in a child process
+    (tools/cpu_baseline.py); falls back to the portable single-thread build."""
+    import subprocess
+    import tempfile
     ms = min(sample_markers, M)
     bed = dev.get_bed(0, ms)
-    g = None if groups is None else np.ascontiguousarray(groups[:ms])
-    ch = orc.Chain(L, bed, N, y, groups=g, mS=np.array(mS), seed=1222, shuffle=1)
-    ch.iterate()  # warm-up iteration (first touch, beta = 0 start)
-    t0 = time.perf_counter()
-    ch.iterate()
-    dt = time.perf_counter() - t0
-    L.orc_set_dot_form(0)
-    return {"value": ms / dt, "unit": "markers/s", "cores": threads, "kind": "port",
-            "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
-                      "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, "
-                      "-O3 -march=native -fopenmp" % (ms, M, N, lib_name)}
+    g = np.zeros(0, dtype=np.int32) if groups is None else np.ascontiguousarray(groups[:ms])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sample.npz")
+        np.savez(path, bed=bed, y=y, N=np.array(N), groups=g, mS=np.array(mS))
+        for lib_name, thr in (("liboracle_omp.so", threads), ("liboracle.so", 1)):
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), path, lib_name, str(thr)],
+                                     capture_output=True, text=True, timeout=900)
+                if out.returncode == 0:
+                    r = json.loads(out.stdout.strip().splitlines()[-1])
+                    flags = "-O3 -march=native -fopenmp" if lib_name == "liboracle_omp.so" else "-O2"
+                    return {"value": r["markers_per_s"], "unit": "markers/s", "cores": thr, "kind": "port",
+                            "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
+                                      "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, %s"
+                                      % (ms, M, N, lib_name, flags)}
+                print("cpu_baseline with %s failed (rc %d): %s" % (lib_name, out.returncode, out.stderr[-400:]), file=sys.stderr)
+            except Exception as e:
+                print("cpu_baseline with %s failed: %r" % (lib_name, e), file=sys.stderr)
+    return None
 
 
 def main():
@@ -314,7 +317,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU
             sample = args.cpu_sample or max(64, min(M, int(4.0e9 / max(1, N))))
-            out["cpu_baseline"] = cpu_baseline(dev, True, y, N, M, mS, groups, sample, threads)
+            out["cpu_baseline"] = cpu_baseline(dev, y, N, M, mS, groups, sample, threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
