@@ -17,7 +17,8 @@ ABI_SYMBOLS = [
     "hgibbs_comm_init", "hgibbs_comm_init_external", "hgibbs_p2p_export", "hgibbs_p2p_import", "hgibbs_load_bed", "hgibbs_synth_bed", "hgibbs_dims", "hgibbs_get_bed",
     "hgibbs_marker_stats", "hgibbs_set_residual", "hgibbs_get_residual", "hgibbs_reduce_eps", "hgibbs_add_scalar",
     "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_covariates", "hgibbs_cov_dot", "hgibbs_cov_update",
-    "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
+    "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_components", "hydra_chain_restore",
+    "hydra_rng_to_boost_words", "hydra_rng_from_boost_words", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
     "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
@@ -31,6 +32,13 @@ class RngState(C.Structure):
 class SweepStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("device_ms", C.c_double),
                 ("kernel_ms_avg", C.c_double)]
+
+
+class RestartState(C.Structure):
+    _fields_ = [("iteration", C.c_uint32), ("sigmaE", C.c_double), ("mu", C.c_double),
+                ("sigmaG", C.POINTER(C.c_double)), ("estPi", C.POINTER(C.c_double)), ("beta", C.POINTER(C.c_double)),
+                ("components", C.POINTER(C.c_int32)), ("eps", C.POINTER(C.c_double)), ("order", C.POINTER(C.c_int32)),
+                ("gamma", C.POINTER(C.c_double)), ("xI", C.POINTER(C.c_int32)), ("rng", RngState)]
 
 
 class ModelDesc(C.Structure):
@@ -82,6 +90,10 @@ def lib():
     L.hgibbs_cov_update.argtypes = [vp, C.c_int, C.c_double]
     L.hydra_chain_set_covariates.argtypes = [vp, dp, C.c_int]
     L.hydra_chain_gamma.argtypes = [vp, dp, ip]
+    L.hgibbs_set_components.argtypes = [vp, ip]
+    L.hydra_chain_restore.argtypes = [vp, C.POINTER(RestartState)]
+    L.hydra_rng_to_boost_words.argtypes = [C.POINTER(RngState), u32p]
+    L.hydra_rng_from_boost_words.argtypes = [u32p, C.POINTER(RngState)]
     L.hgibbs_set_model.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
     L.hgibbs_set_beta.argtypes = [vp, dp]
     L.hgibbs_get_beta.argtypes = [vp, dp, ip, dp]
@@ -339,6 +351,30 @@ class Chain:
 
     def order(self):
         return np.ctypeslib.as_array(self.L.hydra_chain_order(self.h), shape=(self.dev.M,)).copy()
+
+    def rng_words(self):
+        """dist.rng in Boost's stream form (what hydra's .rng.<rank> holds)."""
+        rng = RngState()
+        check(self.L.hydra_chain_state(self.h, None, None, None, None, None, None, C.byref(rng)))
+        out = np.zeros(624, dtype=np.uint32)
+        check(self.L.hydra_rng_to_boost_words(C.byref(rng), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def restore(self, iteration, sigmaE, mu, sigmaG, estPi, beta, components, eps, order, rng_words, gamma=None, xI=None):
+        """init_from_restart: eps = this rank's rows; the chain continues at iteration + 1."""
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = [f64(sigmaG), f64(estPi), f64(beta), i32(components), f64(eps), i32(order)]
+        st = RestartState()
+        st.iteration, st.sigmaE, st.mu = iteration, sigmaE, mu
+        st.sigmaG, st.estPi, st.beta = _dp(keep[0]), _dp(keep[1]), _dp(keep[2])
+        st.components, st.eps, st.order = _ip(keep[3]), _dp(keep[4]), _ip(keep[5])
+        if gamma is not None:
+            keep += [f64(gamma), i32(xI)]
+            st.gamma, st.xI = _dp(keep[6]), _ip(keep[7])
+        w = np.ascontiguousarray(rng_words, dtype=np.uint32)
+        check(self.L.hydra_rng_from_boost_words(w.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st.rng)))
+        check(self.L.hydra_chain_restore(self.h, C.byref(st)))
 
     def last_nnz(self):
         return int(self.L.hydra_chain_last_nnz(self.h))

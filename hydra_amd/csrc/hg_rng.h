@@ -12,6 +12,9 @@
 
 #include <math.h>
 #include <stdint.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <vector>
+#endif
 
 #include "hg_zig_tables.h"
 
@@ -207,6 +210,41 @@ inline void dirichlet_rng(Mt& g, const double* alpha, int len, double* out)
     for (int i = 0; i < len; ++i) out[i] = rgamma(g, alpha[i], 1.0);
     for (int i = 0; i < len; ++i) s += out[i];
     for (int i = 0; i < len; ++i) out[i] /= s;
+}
+
+// Boost.Random's stream form of mersenne_twister_engine (what `file << rng` writes at
+// src/distributions_boost.cpp:38-44): the n words of the window that ENDS just before the
+// next output, so that a reader can load them and set i = n (operator>> does exactly that,
+// :46-55).  The last idx words are the consumed part of the current block; the first
+// n - idx words belong to the previous block and are recovered by running the recurrence
+// backwards: each step yields the top bit of word k and the low 31 bits of word k+1.
+inline void mt_to_boost_words(const uint32_t* x, uint32_t idx, uint32_t* out /* 624 */)
+{
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    if (idx > (uint32_t)MT_N) idx = MT_N;
+    for (uint32_t j = 0; j < idx; ++j) out[j + MT_N - idx] = x[j];
+    if (idx == (uint32_t)MT_N) return;
+    // word w(k), k in [idx, n): previous block's entry k; known: current block x[0..n)
+    // x[k] = far(k) ^ G(w(k), w(k+1)),  far(k) = w(k+m) for k+m < n else x[k+m-n];  w(n) := x[0]
+    auto unmix = [&](uint32_t y) { // y = G(a,b) -> (top bit of a) | (low 31 bits of b)
+        if (y & UP) return ((y ^ A) << 1) | 1u;
+        return y << 1;
+    };
+    std::vector<uint32_t> w(MT_N + 1, 0u);
+    w[MT_N] = x[0];
+    // step k gives top bit of w(k) and low bits of w(k+1); go from k = n-1 down to idx-1
+    uint32_t have_low_of = MT_N; // w[MT_N] fully known
+    (void)have_low_of;
+    for (int k = MT_N - 1; k >= (int)idx - 1 && k >= 0; --k) {
+        const uint32_t far = (k + MT_M < MT_N) ? w[k + MT_M] : x[k + MT_M - MT_N];
+        const uint32_t y = unmix(x[k] ^ far);
+        // low 31 bits of w(k+1) (consistency only for k+1 == n) and top bit of w(k)
+        if (k + 1 < MT_N) w[k + 1] = (w[k + 1] & UP) | (y & LO);
+        w[k] = (w[k] & LO) | (y & UP);
+    }
+    // the top bit of w(idx) came from step idx, its low bits from step idx-1 (when idx > 0);
+    // for idx == 0 the low bits of w(0) are never used by the forward recurrence: leave them 0
+    for (uint32_t k = idx; k < (uint32_t)MT_N; ++k) out[k - idx] = w[k];
 }
 
 // URBG view for std::shuffle (src/BayesRRm.cpp:1692 passes dist.rng)

@@ -963,6 +963,14 @@ int hgibbs_set_beta(hgibbs_t h, const double* beta_host)
     return 0;
 }
 
+int hgibbs_set_components(hgibbs_t h, const int32_t* components_host)
+{
+    if (!h || !h->bed || !components_host) return fail("hgibbs_set_components: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->comp, components_host, (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int hgibbs_get_beta(hgibbs_t h, double* beta_host, int32_t* components_host, double* acum_host)
 {
     if (!h || !h->bed) return fail("hgibbs_get_beta: no data loaded");
@@ -1181,6 +1189,10 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out)", dh.error, dh.cursor);
         if (dh.launches > 0) avg_accept = std::max(1.0, (double)dh.accepted_sum / (double)dh.launches);
         if (dh.cursor >= M && dh.pend_marker[0] < 0) break;
+        // every launch accepts at least one marker or flushes a pending update: a sweep that needs more
+        // than 2M launches (plus one chunk of overshoot) is stuck, not slow
+        if (total_launches > 2ull * M + 4096)
+            return fail("hgibbs_sweep: no progress after %llu launches (cursor %u of %u)", (unsigned long long)total_launches, dh.cursor, M);
     }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));

@@ -277,6 +277,49 @@ int hydra_chain_set_covariates(hydra_chain_t c, const double* X_host, int C)
     return hgibbs_set_covariates(c->dev, C ? X_host + (size_t)c->row_begin * C : nullptr, C);
 }
 
+int hydra_chain_restore(hydra_chain_t c, const hydra_restart_state* st)
+{
+    if (!c || !st || !st->sigmaG || !st->estPi || !st->beta || !st->components || !st->eps || !st->order)
+        return cfail("hydra_chain_restore: null argument");
+    if (c->C > 0 && (!st->gamma || !st->xI)) return cfail("hydra_chain_restore: covariates set but no gamma/xI given");
+    const int G = c->G, K = c->K;
+    c->sigmaE = st->sigmaE;
+    c->mu = st->mu;
+    std::copy(st->sigmaG, st->sigmaG + G, c->sigmaG.begin());
+    std::copy(st->estPi, st->estPi + (size_t)G * K, c->estPi.begin());
+    for (uint32_t i = 0; i < c->M; ++i) {
+        if (st->order[i] < 0 || (uint32_t)st->order[i] >= c->M) return cfail("hydra_chain_restore: marker index out of range");
+        c->order[i] = st->order[i];
+    }
+    for (int i = 0; i < c->C; ++i) {
+        c->gamma[i] = st->gamma[i];
+        c->xI[i] = (unsigned)st->xI[i];
+    }
+    c->rng = st->rng;
+    if (hgibbs_set_beta(c->dev, st->beta)) return 1;
+    if (hgibbs_set_components(c->dev, st->components)) return 1;
+    if (hgibbs_set_residual(c->dev, st->eps)) return 1;
+    // adaV is rebuilt from sigmaG as after init_from_restart (src/BayesRRm.cpp:1592-1597)
+    for (uint32_t i = 0; i < c->M; ++i) c->adaV[i] = (c->sigmaG[c->groups[i]] == 0.0) ? 0 : 1;
+    c->iteration = st->iteration + 1;
+    return 0;
+}
+
+int hydra_rng_to_boost_words(const hgibbs_rng_state* st, uint32_t* words624)
+{
+    if (!st || !words624) return cfail("hydra_rng_to_boost_words: null argument");
+    hg::mt_to_boost_words(st->x, st->idx, words624);
+    return 0;
+}
+
+int hydra_rng_from_boost_words(const uint32_t* words624, hgibbs_rng_state* st)
+{
+    if (!st || !words624) return cfail("hydra_rng_from_boost_words: null argument");
+    std::memcpy(st->x, words624, 624 * sizeof(uint32_t));
+    st->idx = 624; // mt.i = mt.state_size
+    return 0;
+}
+
 int hydra_chain_gamma(hydra_chain_t c, double* gamma_out, int32_t* xI_out)
 {
     if (!c) return cfail("hydra_chain_gamma: null chain");

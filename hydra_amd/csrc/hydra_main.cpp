@@ -6,10 +6,12 @@
 // files (.bed/.bim/.fam, .phen with NA, --groupIndexFile/--groupMixtureFile),
 // same output files and byte layouts (src/BayesRRm.cpp:1071-1083,1299-1309,
 // 2736-2794): <dir>/<name>.csv .bet .cpn .acu .mus.<rank>, and on --save
-// .eps.<rank> .mrk.<rank> .xbet .xcpn (:2802-2838).
+// .eps.<rank> .mrk.<rank> .rng.<rank> .xbet .xcpn (:2802-2838); --restart
+// [--ignore-xfiles] resumes from those dumps into <name>_rs.* (:842-928,
+// :1197-1220).
 //
 // Not reproduced (out of scope for the hot path): sparse
-// file formats, --restart, bayesFH/bayesW, marker-sharded MPI.
+// file formats, bayesFH/bayesW, marker-sharded MPI, the .lst/tarball.
 // Multi-GPU: one process per GPU (RANK/WORLD_SIZE/LOCAL_RANK in the
 // environment, as torchrun/mpirun export them); individuals are sharded and the
 // ncclUniqueId travels through a file in --mcmc-out-dir.
@@ -45,6 +47,7 @@ struct Options { // src/options.hpp:20-138 (subset that reaches bayesMPI)
     int shuffleMarkers = 1, syncRate = 1;
     std::vector<double> S{0.01, 0.001, 0.0001};
     bool readFromBedFile = false;
+    bool restart = false, useXfilesInRestart = true; // options.hpp:33-34
     int batch = 0, cpg = 0; // tuning knobs of this build (not hydra's)
 };
 
@@ -108,7 +111,9 @@ Options parse(int argc, const char* argv[])
         else if (a == "--covariates") {
             o.covariates = true;
             o.covariatesFile = need(i);
-        } else if (a == "--sparse-dir" || a == "--sparse-basename" || a == "--restart" ||
+        } else if (a == "--restart") o.restart = true;          // options.cpp:63-65
+        else if (a == "--ignore-xfiles") o.useXfilesInRestart = false; // options.cpp:67-69
+        else if (a == "--sparse-dir" || a == "--sparse-basename" ||
                  a == "--bed-to-sparse" || a == "--sparse-sync" || a == "--bed-sync" || a == "--failure" || a == "--quad_points")
             fatal("FATAL  : option " + a + " belongs to a part of hydra this build does not reproduce (SURVEY.md section 2)");
         else
@@ -262,6 +267,124 @@ double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// ---- restart readers: Data::read_mcmc_output_*_file, src/data.cpp:33-519 ----
+struct CsvRestart {
+    unsigned iteration_to_restart_from = 0, first_thinned_iteration = 0, first_saved_iteration = 0;
+    std::vector<double> sigmaG, pi;
+    double sigmaE = 0.0;
+};
+
+// data.cpp:406-514: the last line whose iteration is a multiple of --save wins
+CsvRestart read_csv_for_restart(const std::string& csv, unsigned thin, unsigned save, int G, int K)
+{
+    std::ifstream file(csv);
+    if (!file) fatal("*FATAL*: failed to open csv file " + csv + "!");
+    CsvRestart r;
+    r.sigmaG.assign(G, 0.0);
+    r.pi.assign((size_t)G * K, 0.0);
+    int nSaved = 0, nThinned = 0, last_it = -1;
+    std::string str;
+    while (std::getline(file, str)) {
+        if (str.empty()) continue;
+        for (char& ch : str)
+            if (ch == ',') ch = ' ';
+        char* p = &str[0];
+        const long it = std::strtol(p, &p, 10);
+        const long ngrp = std::strtol(p, &p, 10);
+        last_it = (int)it;
+        if (it % thin != 0) fatal("FATAL  : " + csv + ": iteration " + std::to_string(it) + " is not a multiple of --thin");
+        if (++nThinned == 1) r.first_thinned_iteration = (unsigned)it;
+        if (it % save != 0) continue;
+        if (++nSaved == 1) r.first_saved_iteration = (unsigned)it;
+        r.iteration_to_restart_from = (unsigned)it;
+        if (ngrp != G) fatal("FATAL  : " + csv + ": number of groups differs from this run's");
+        for (int g = 0; g < G; ++g) r.sigmaG[g] = std::strtod(p, &p);
+        r.sigmaE = std::strtod(p, &p);
+        (void)std::strtod(p, &p);      // sigmaG.sum()/(sigmaE+sigmaG.sum())
+        (void)std::strtol(p, &p, 10);  // m0
+        const long rows = std::strtol(p, &p, 10), cols = std::strtol(p, &p, 10);
+        if (rows != G || cols != K) fatal("FATAL  : " + csv + ": pi is " + std::to_string(rows) + "x" + std::to_string(cols) + ", expected " + std::to_string(G) + "x" + std::to_string(K));
+        for (size_t i = 0; i < (size_t)G * K; ++i) r.pi[i] = std::strtod(p, &p);
+    }
+    if (nSaved == 0)
+        fatal("FATAL  : No saved iteration could be found when reading " + csv + "!\n       : with last read iteration " + std::to_string(last_it) +
+              ", and --thin = " + std::to_string(thin) + " and --save = " + std::to_string(save));
+    return r;
+}
+
+void pread_at(FILE* f, long off, void* dst, size_t n, const std::string& what)
+{
+    if (std::fseek(f, off, SEEK_SET) != 0 || std::fread(dst, 1, n, f) != n) fatal("FATAL  : short read from " + what);
+}
+
+FILE* open_ro(const std::string& p)
+{
+    FILE* f = std::fopen(p.c_str(), "rb");
+    if (!f) fatal("FATAL  : can not open " + p + " to restart from");
+    return f;
+}
+
+void expect_u(unsigned got, unsigned want, const std::string& what)
+{
+    if (got != want) fatal("Mismatch between expected and read " + what + ": " + std::to_string(want) + " vs " + std::to_string(got));
+}
+
+// .bet/.cpn history (elem = 8/4 bytes) or the single-line .xbet/.xcpn, data.cpp:256-402
+void read_marker_history(const std::string& path, bool xfile, unsigned Mtot, unsigned it_from, unsigned first_thinned, unsigned thin, size_t elem,
+                         void* dst)
+{
+    FILE* f = open_ro(path);
+    unsigned Mtot_ = 0, it_ = ~0u;
+    pread_at(f, 0, &Mtot_, sizeof(unsigned), path);
+    expect_u(Mtot_, Mtot, path + " Mtot");
+    if ((it_from - first_thinned) % thin != 0) fatal("FATAL  : " + path + ": restart iteration is not on the --thin grid");
+    const long n_skip = (long)((it_from - first_thinned) / thin);
+    const long off = xfile ? (long)sizeof(unsigned) : (long)sizeof(unsigned) + n_skip * (long)(sizeof(unsigned) + (size_t)Mtot * elem);
+    pread_at(f, off, &it_, sizeof(unsigned), path);
+    expect_u(it_, it_from, path + " iteration");
+    pread_at(f, off + (long)sizeof(unsigned), dst, (size_t)Mtot * elem, path);
+    std::fclose(f);
+}
+
+// .eps/.mrk/.gam/.xiv dumps: (iteration, length, payload), data.cpp:33-204
+std::vector<uint8_t> read_dump(const std::string& path, unsigned it_from, size_t elem, unsigned* length)
+{
+    FILE* f = open_ro(path);
+    unsigned it_ = ~0u, len = 0;
+    pread_at(f, 0, &it_, sizeof(unsigned), path);
+    expect_u(it_, it_from, path + " iteration");
+    pread_at(f, sizeof(unsigned), &len, sizeof(unsigned), path);
+    std::vector<uint8_t> out((size_t)len * elem);
+    pread_at(f, 2 * sizeof(unsigned), out.data(), out.size(), path);
+    std::fclose(f);
+    *length = len;
+    return out;
+}
+
+// `file >> rng` for boost::mt19937, src/distributions_boost.cpp:46-55: 624 decimal words
+void read_rng_file(const std::string& path, hgibbs_rng_state* st)
+{
+    std::ifstream in(path);
+    if (!in) fatal("*FATAL*: Unable to read from file " + path);
+    std::vector<uint32_t> w(624);
+    for (int i = 0; i < 624; ++i) {
+        unsigned long long v = 0;
+        if (!(in >> v) || v > 0xffffffffull) fatal("*FATAL*: " + path + " does not hold a boost::mt19937 state");
+        w[i] = (uint32_t)v;
+    }
+    hydra_rng_from_boost_words(w.data(), st);
+}
+
+// `file << rng`, src/distributions_boost.cpp:38-44: words separated by single spaces
+void write_rng_file(const std::string& path, const hgibbs_rng_state& st)
+{
+    std::vector<uint32_t> w(624);
+    hydra_rng_to_boost_words(&st, w.data());
+    std::ofstream out(path, std::ios::out | std::ios::trunc | std::ios::binary);
+    if (!out) fatal("FATAL  : can not create " + path);
+    for (int i = 0; i < 624; ++i) out << w[i] << (i + 1 < 624 ? " " : "");
+}
+
 } // namespace
 
 int main(int argc, const char* argv[])
@@ -345,7 +468,9 @@ int main(int argc, const char* argv[])
     struct stat sb;
     if (stat(opt.mcmcOutDir.c_str(), &sb) != 0 && rank == 0)
         if (std::system(("mkdir -p " + opt.mcmcOutDir).c_str()) != 0) fatal("FATAL  : can not create --mcmc-out-dir");
-    const std::string base = opt.mcmcOutDir + "/" + opt.mcmcOutNam;
+    // a restart reads <name>.* and writes <name>_rs.* so the failed job's files stay untouched (:1206-1220)
+    const std::string base_in = opt.mcmcOutDir + "/" + opt.mcmcOutNam;
+    const std::string base = opt.restart ? base_in + "_rs" : base_in;
 
     // ---- device -------------------------------------------------------------
     hgibbs_t dev = nullptr;
@@ -461,6 +586,77 @@ int main(int argc, const char* argv[])
         hg_check(hydra_chain_set_covariates(chain, covX.data(), C), "hydra_chain_set_covariates");
     }
 
+    // ---- --restart: BayesRRm::init_from_restart, :842-928, then :1546-1597 -----
+    unsigned iteration_start = 0;
+    if (opt.restart) {
+        if (rank == 0) std::printf("RESTART: from files: %s.* files\n", base_in.c_str());
+        const CsvRestart cr = read_csv_for_restart(base_in + ".csv", opt.thin, opt.save, G, K);
+        if (rank == 0) {
+            std::printf("RESTART: Reading .cvs file %s\n", (base_in + ".csv").c_str());
+            std::printf("RESTART: --thin %d  -- save %d\n", opt.thin, opt.save);
+            std::printf("RESTART: iteration_to_restart_from = %d\n", cr.iteration_to_restart_from);
+            std::printf("RESTART: first_thinned_iteration   = %d\n", cr.first_thinned_iteration);
+            std::printf("RESTART: first_saved_iteration     = %d\n", cr.first_saved_iteration);
+        }
+        if (cr.iteration_to_restart_from == 0)
+            fatal("FATAL  : There is no point in restarting a chain from iteration 0 (not saved anyway)\n         => restart your analysis from scratch");
+        const unsigned it_from = cr.iteration_to_restart_from;
+        const bool xf = opt.useXfilesInRestart;
+        std::vector<double> r_beta(Mtot);
+        std::vector<int32_t> r_comp(Mtot);
+        read_marker_history(base_in + (xf ? ".xbet" : ".bet"), xf, Mtot, it_from, cr.first_thinned_iteration, opt.thin, sizeof(double), r_beta.data());
+        read_marker_history(base_in + (xf ? ".xcpn" : ".cpn"), xf, Mtot, it_from, cr.first_thinned_iteration, opt.thin, sizeof(int32_t), r_comp.data());
+        double r_mu = 0.0;
+        { // .mus.<rank>: (iteration, mu) per thinned iteration, data.cpp:207-252
+            const std::string mp = base_in + ".mus." + std::to_string(rank);
+            FILE* f = open_ro(mp);
+            const long off = (long)((it_from - cr.first_thinned_iteration) / opt.thin) * (long)(sizeof(unsigned) + sizeof(double));
+            unsigned it_ = ~0u;
+            pread_at(f, off, &it_, sizeof(unsigned), mp);
+            expect_u(it_, it_from, mp + " iteration");
+            pread_at(f, off + (long)sizeof(unsigned), &r_mu, sizeof(double), mp);
+            std::fclose(f);
+        }
+        unsigned len = 0;
+        // .eps.<rank>: this rank's shard; a full-length dump (hydra's own, or a 1-rank run's) is sliced
+        std::vector<uint8_t> eb = read_dump(base_in + ".eps." + std::to_string(rank), it_from, sizeof(double), &len);
+        const double* r_eps = (const double*)eb.data();
+        if (len == Ntot && len != hi - lo) r_eps += lo;
+        else expect_u(len, hi - lo, ".eps Ntot");
+        std::vector<uint8_t> mb = read_dump(base_in + ".mrk." + std::to_string(rank), it_from, sizeof(int32_t), &len);
+        expect_u(len, Mtot, ".mrk M");
+        std::vector<uint8_t> gb, xb;
+        if (opt.covariates) {
+            gb = read_dump(base_in + ".gam." + std::to_string(rank), it_from, sizeof(double), &len);
+            expect_u(len, (unsigned)C, ".gam length");
+            xb = read_dump(base_in + ".xiv." + std::to_string(rank), it_from, sizeof(int32_t), &len);
+            expect_u(len, (unsigned)C, ".xiv length");
+        }
+        hydra_restart_state rs{};
+        rs.iteration = it_from;
+        rs.sigmaE = cr.sigmaE;
+        rs.mu = r_mu;
+        rs.sigmaG = cr.sigmaG.data();
+        rs.estPi = cr.pi.data();
+        rs.beta = r_beta.data();
+        rs.components = r_comp.data();
+        rs.eps = r_eps;
+        rs.order = (const int32_t*)mb.data();
+        rs.gamma = opt.covariates ? (const double*)gb.data() : nullptr;
+        rs.xI = opt.covariates ? (const int32_t*)xb.data() : nullptr;
+        read_rng_file(base_in + ".rng." + std::to_string(rank), &rs.rng);
+        hg_check(hydra_chain_restore(chain, &rs), "hydra_chain_restore");
+        iteration_start = it_from + 1;
+        if (rank == 0) { // Data::print_restart_banner, data.cpp:20-31
+            std::printf("INFO   : %s\n", std::string(100, '*').c_str());
+            std::printf("INFO   : RESTART DETECTED\n");
+            std::printf("INFO   : restarting from: %s.* files\n", base_in.c_str());
+            std::printf("INFO   : last saved iteration:        %d\n", it_from);
+            std::printf("INFO   : will restart from iteration: %d\n", iteration_start);
+            std::printf("INFO   : %s\n", std::string(100, '*').c_str());
+        }
+    }
+
     // ---- outputs (rank 0 writes the shared files) ----------------------------
     FILE *outf = nullptr, *betf = nullptr, *cpnf = nullptr, *acuf = nullptr, *xbetf = nullptr, *xcpnf = nullptr;
     auto open_trunc = [&](const std::string& p) {
@@ -493,7 +689,7 @@ int main(int argc, const char* argv[])
     unsigned n_thinned_saved = 0;
     const double t_all = now_s();
 
-    for (unsigned iteration = 0; iteration < opt.chainLength; ++iteration) {
+    for (unsigned iteration = iteration_start; iteration < opt.chainLength; ++iteration) {
         const double t0 = now_s();
         hg_check(hydra_chain_iterate(chain), "hydra_chain_iterate");
         const double t1 = now_s();
@@ -532,7 +728,10 @@ int main(int argc, const char* argv[])
             n_thinned_saved += 1;
         }
 
-        if (iteration > 0 && iteration % opt.save == 0) { // :2802-2838 (no .rng text dump, no tarball)
+        if (iteration > 0 && iteration % opt.save == 0) { // :2802-2838 (no tarball)
+            hgibbs_rng_state rst;
+            hydra_chain_state(chain, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &rst);
+            write_rng_file(base + ".rng." + std::to_string(rank), rst);
             hg_check(hgibbs_get_residual(dev, eps.data()), "hgibbs_get_residual");
             const unsigned nloc = hi - lo;
             pwrite_at(epsf, 0, &iteration, sizeof(unsigned));

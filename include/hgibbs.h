@@ -127,6 +127,7 @@ int hgibbs_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const
 
 /* ---- marker effects (replicated on every rank) --------------------------- */
 int hgibbs_set_beta(hgibbs_t h, const double* beta_host);
+int hgibbs_set_components(hgibbs_t h, const int32_t* components_host); /* restart only */
 int hgibbs_get_beta(hgibbs_t h, double* beta_host, int32_t* components_host, double* acum_host);
 /* per-group sum of beta^2 in marker order (src/BayesRRm.cpp:2496-2499) */
 int hgibbs_beta_sqnorm(hgibbs_t h, double* bsq_host /* G */);
@@ -184,6 +185,29 @@ int hydra_chain_state(hydra_chain_t c, double* sigmaE, double* mu, double* sigma
 /* the .csv line of src/BayesRRm.cpp:2742-2760 for the given iteration number */
 int hydra_chain_csv_line(hydra_chain_t c, uint32_t iteration, char* buf, size_t len);
 const int32_t* hydra_chain_order(hydra_chain_t c);
+
+/* ---- checkpoint / restart (src/BayesRRm.cpp:842-928, :2802-2838) --------- */
+/* State a --restart run reads back from the dump files; arrays are host
+ * pointers, eps has this rank's individuals.  gamma/xI may be NULL without
+ * covariates.  `iteration` = the saved iteration; the chain continues at +1. */
+typedef struct {
+    uint32_t iteration;
+    double sigmaE, mu;
+    const double* sigmaG;        /* G */
+    const double* estPi;         /* G*K */
+    const double* beta;          /* M */
+    const int32_t* components;   /* M */
+    const double* eps;           /* n_local */
+    const int32_t* order;        /* M: markerI as dumped in .mrk */
+    const double* gamma;         /* C or NULL */
+    const int32_t* xI;           /* C or NULL */
+    hgibbs_rng_state rng;
+} hydra_restart_state;
+int hydra_chain_restore(hydra_chain_t c, const hydra_restart_state* st);
+/* dist.rng in Boost's stream form (624 decimal words, `file << rng`,
+ * src/distributions_boost.cpp:38-44) and back (`file >> rng`, :46-55) */
+int hydra_rng_to_boost_words(const hgibbs_rng_state* st, uint32_t* words624);
+int hydra_rng_from_boost_words(const uint32_t* words624, hgibbs_rng_state* st);
 /* markers with deltaBeta != 0 in the last sweep */
 uint64_t hydra_chain_last_nnz(hydra_chain_t c);
 

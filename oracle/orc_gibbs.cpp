@@ -629,6 +629,34 @@ void orc_chain_set_covariates(orc_chain* c, const double* X, int C)
     for (int i = 0; i < C; ++i) c->xI[i] = (unsigned)i;
 }
 double* orc_chain_gamma(orc_chain* c) { return c->gamma.data(); }
+unsigned int* orc_chain_xI(orc_chain* c) { return c->xI.data(); }
+
+/* Restart: what runMpiGibbs does with the *_restart members after init_from_restart
+ * (src/BayesRRm.cpp:842-928 reads them; :1546-1573 installs gamma/xI/epsilon/markerI/mu;
+ * :1592-1597 rebuilds adaV; :924 iteration_start = it + 1).  Beta and components were read
+ * straight into the live vectors (:881-896). */
+void orc_chain_restore(orc_chain* c, uint32_t iteration, double sigmaE, double mu, const double* sigmaG,
+                       const double* estPi, const double* beta, const int* components, const double* eps,
+                       const int* order, const double* gamma, const int* xI, const uint32_t* rng_words)
+{
+    c->sigmaE = sigmaE;
+    c->mu = mu;
+    for (int g = 0; g < c->G; ++g) c->sigmaG[g] = sigmaG[g];
+    for (int i = 0; i < c->G * c->K; ++i) c->estPi[i] = estPi[i];
+    for (uint32_t i = 0; i < c->M; ++i) {
+        c->beta[i] = beta[i];
+        c->components[i] = components[i];
+        c->order[i] = order[i];
+    }
+    for (uint32_t i = 0; i < c->N; ++i) c->eps[i] = eps[i];
+    for (int i = 0; i < c->C; ++i) {
+        c->gamma[i] = gamma[i];
+        c->xI[i] = (unsigned)xI[i];
+    }
+    for (uint32_t i = 0; i < c->M; ++i) c->adaV[i] = (c->sigmaG[c->groups[i]] == 0.0) ? 0 : 1;
+    orc_mt_load_words(&c->rng, rng_words);
+    c->iteration = iteration + 1;
+}
 
 void orc_chain_iterate(orc_chain* c)
 {
@@ -680,6 +708,8 @@ int orc_chain_csv_line(orc_chain* c, uint32_t iteration, char* buf, size_t len)
 
 /* ---- RNG known-answer entry points for tests ---- */
 void orc_rng_seed(orc_mt* g, uint32_t seed) { orc_mt_seed(g, seed); }
+void orc_rng_print_words(const orc_mt* g, uint32_t* out624) { orc_mt_print_words(g, out624); }
+void orc_rng_load_words(orc_mt* g, const uint32_t* in624) { orc_mt_load_words(g, in624); }
 uint32_t orc_rng_u32(orc_mt* g) { return orc_mt_next(g); }
 double orc_rng_unif(orc_mt* g) { return orc_unif_rng(g); }
 double orc_rng_norm(orc_mt* g, double mean, double var) { return orc_norm_rng(g, mean, var); }

@@ -84,6 +84,47 @@ static inline uint32_t orc_mt_next(orc_mt* g)
 
 /* uniform_01<double> / uniform_real_distribution<double>(0,1) on mt19937:
  * numerator / 2^32, retried while the result is not < 1 (never for 32 bits). */
+/* Stream form of boost::random::mersenne_twister_engine (Boost 1.67,
+ * boost/random/mersenne_twister.hpp: print(), rewind(), rewind_find(); operator>> reads n
+ * words and sets i = n).  hydra dumps/restores dist.rng this way
+ * (src/distributions_boost.cpp:38-55).  The n printed words are the window ending right
+ * before the next output: the i consumed words of the current block go last, the n - i words
+ * before them are recovered by running the recurrence backwards. */
+static inline uint32_t orc_mt_rewind_find(const orc_mt* g, const uint32_t* last, size_t size, size_t j)
+{
+    const size_t n = ORC_MT_N;
+    const size_t index = (j + n - size + n - 1) % n;
+    if (index < n - size) return g->x[index];
+    return *(last - (n - 1 - index));
+}
+
+static inline void orc_mt_rewind(const orc_mt* g, uint32_t* last, size_t z)
+{
+    const uint32_t upper = 0x80000000u, lower = 0x7fffffffu, a = 0x9908b0dfu;
+    uint32_t y0 = g->x[ORC_MT_M - 1] ^ g->x[ORC_MT_N - 1];
+    y0 = (y0 & upper) ? (((y0 ^ a) << 1) | 1u) : (y0 << 1);
+    for (size_t sz = 0; sz < z; ++sz) {
+        uint32_t y1 = orc_mt_rewind_find(g, last, sz, ORC_MT_M - 1) ^ orc_mt_rewind_find(g, last, sz, ORC_MT_N - 1);
+        y1 = (y1 & upper) ? (((y1 ^ a) << 1) | 1u) : (y1 << 1);
+        *(last - sz) = (y0 & upper) | (y1 & lower);
+        y0 = y1;
+    }
+}
+
+static inline void orc_mt_print_words(const orc_mt* g, uint32_t* data /* n */)
+{
+    const size_t n = ORC_MT_N;
+    size_t i = g->idx > n ? n : g->idx;
+    for (size_t j = 0; j < i; ++j) data[j + n - i] = g->x[j];
+    if (i != n) orc_mt_rewind(g, &data[n - i - 1], n - i);
+}
+
+static inline void orc_mt_load_words(orc_mt* g, const uint32_t* data /* n */)
+{
+    for (int j = 0; j < ORC_MT_N; ++j) g->x[j] = data[j];
+    g->idx = ORC_MT_N;
+}
+
 static inline double orc_unif01(orc_mt* g)
 {
     return (double)orc_mt_next(g) * (1.0 / 4294967296.0);

@@ -51,6 +51,13 @@ def load(name="liboracle.so"):
     L.orc_chain_set_covariates.argtypes = [C.c_void_p, dp, C.c_int]
     L.orc_chain_gamma.argtypes = [C.c_void_p]
     L.orc_chain_gamma.restype = dp
+    L.orc_chain_xI.argtypes = [C.c_void_p]
+    L.orc_chain_xI.restype = C.POINTER(C.c_uint32)
+    u32p = C.POINTER(C.c_uint32)
+    L.orc_chain_restore.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, dp, dp, dp, ip, dp, ip, dp, ip, u32p]
+    L.orc_chain_restore.restype = None
+    L.orc_rng_print_words.argtypes = [mtp, u32p]
+    L.orc_rng_load_words.argtypes = [mtp, u32p]
     L.orc_chain_sweep.argtypes = [C.c_void_p]
     L.orc_chain_sweep.restype = C.c_long
     for f in ("beta", "acum", "eps", "y", "sigmaG", "estPi", "mave", "mstd", "cVa", "cVaI"):
@@ -161,6 +168,24 @@ class Chain:
 
     def gamma(self):
         return np.ctypeslib.as_array(self.L.orc_chain_gamma(self.h), shape=(self.C,)).copy()
+
+    def xI(self):
+        return np.ctypeslib.as_array(self.L.orc_chain_xI(self.h), shape=(self.C,)).astype(np.int32)
+
+    def rng_words(self):
+        """dist.rng as `file << rng` prints it (624 words)."""
+        out = np.zeros(624, dtype=np.uint32)
+        self.L.orc_rng_print_words(self.L.orc_chain_rng(self.h), p(out, C.c_uint32))
+        return out
+
+    def restore(self, iteration, sigmaE, mu, sigmaG, estPi, beta, components, eps, order, rng_words, gamma=None, xI=None):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = [f64(sigmaG), f64(estPi), f64(beta), i32(components), f64(eps), i32(order),
+                f64(gamma if gamma is not None else np.zeros(1)), i32(xI if xI is not None else np.zeros(1)),
+                np.ascontiguousarray(rng_words, dtype=np.uint32)]
+        self.L.orc_chain_restore(self.h, iteration, sigmaE, mu, dptr(keep[0]), dptr(keep[1]), dptr(keep[2]), iptr(keep[3]),
+                                 dptr(keep[4]), iptr(keep[5]), dptr(keep[6]), iptr(keep[7]), p(keep[8], C.c_uint32))
 
     def iterate(self):
         self.L.orc_chain_iterate(self.h)

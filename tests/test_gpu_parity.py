@@ -608,3 +608,144 @@ def test_cli_covariates_with_na(oracle, tmp_path):
     raw = open(out + "/r.gam.0", "rb").read()
     it_s, glen = struct.unpack("<II", raw[:8])
     assert (it_s, glen) == (4, C) and close(np.frombuffer(raw[8:8 + 8 * C], dtype=np.float64), gam_it4)
+
+
+# ---- checkpoint / restart (src/BayesRRm.cpp:842-928, :2802-2838) --------------
+@pytest.mark.parametrize("with_cov", [False, True])
+def test_chain_restore_continues_the_chain(oracle, with_cov):
+    """Dump at iteration 3 with full precision, restore into a fresh device + chain: the
+    continuation is the uninterrupted chain, bit for bit, and matches the oracle's mirror."""
+    M, N, C_ = 150, 2300, 2
+    geno, y, X = _cov_case(M, N, C_, seed=61)
+    bed = synth.pack_bed_columns(geno)
+
+    def fresh(seed):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("gram", 0)
+        ch = capi.Chain(dev, y, seed=seed)
+        if with_cov:
+            ch.set_covariates(X)
+        return dev, ch
+
+    dev_a, a = fresh(23)
+    ref = orc.Chain(oracle, bed, N, y, seed=23)
+    if with_cov:
+        ref.set_covariates(X)
+    for _ in range(4):
+        a.iterate()
+        ref.iterate()
+    st = a.state()
+    beta, comp, _ = dev_a.get_beta()
+    snap = dict(iteration=3, sigmaE=st["sigmaE"], mu=st["mu"], sigmaG=st["sigmaG"], estPi=st["estPi"], beta=beta,
+                components=comp, eps=dev_a.get_residual(), order=a.order(), rng_words=a.rng_words())
+    if with_cov:
+        g, xi = a.gamma()
+        snap.update(gamma=g, xI=xi)
+    assert np.array_equal(snap["rng_words"], ref.rng_words())  # same stream position, same 624 printed words
+    dev_b, b = fresh(4242)
+    b.restore(**snap)
+    ref_b = orc.Chain(oracle, bed, N, y, seed=1)
+    if with_cov:
+        ref_b.set_covariates(X)
+    ref_b.restore(**snap)
+    for it in range(4, 8):
+        a.iterate()
+        b.iterate()
+        ref_b.iterate()
+        ba, ca, _ = dev_a.get_beta()
+        bb, cb, _ = dev_b.get_beta()
+        assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+        assert np.array_equal(dev_a.get_residual(), dev_b.get_residual())
+        sa, sb = a.state(), b.state()
+        assert sa["sigmaE"] == sb["sigmaE"] and sa["mu"] == sb["mu"] and np.array_equal(sa["sigmaG"], sb["sigmaG"])
+        assert a.csv_line(it) == b.csv_line(it)
+        assert np.array_equal(cb, ref_b.arr("components")) and close(bb, ref_b.arr("beta")) and close(sb["sigmaE"], ref_b.sigmaE)
+
+
+def _dump(path, dtype):
+    raw = open(path, "rb").read()
+    it, n = struct.unpack("<II", raw[:8])
+    return it, np.frombuffer(raw[8:8 + n * np.dtype(dtype).itemsize], dtype=dtype)
+
+
+def test_cli_restart_from_dump_files(oracle, tmp_path):
+    """6 iterations with --save 3 (one dump, at iteration 3), then --restart up to 9: <name>_rs.* carry
+    iterations 4..8 and equal the oracle restored from the very same files (hyper-parameters at the
+    .csv's printed precision, as init_from_restart takes them)."""
+    M, N, C_ = 100, 450, 2
+    geno, y, X = _cov_case(M, N, C_, seed=71)
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, synth.pack_bed_columns(geno), N, y=y)
+    with open(prefix + ".cov", "w") as f:
+        for i in range(N):
+            f.write("fam%d ind%d %r %r\n" % (i, i, float(X[i, 0]), float(X[i, 1])))
+    base = [EXE, "--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--covariates", prefix + ".cov",
+            "--mcmc-out-dir", out, "--mcmc-out-name", "r", "--number-individuals", str(N), "--number-markers", str(M),
+            "--thin", "1", "--save", "3", "--seed", "8", "--S", "0.0001,0.001,0.01"]
+    r = subprocess.run(base + ["--chain-length", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    words = np.array(open(out + "/r.rng.0").read().split(), dtype=np.uint64)
+    assert words.shape == (624,) and words.max() < 2 ** 32
+    first = {p: open(out + "/" + p, "rb").read() for p in ("r.csv", "r.bet", "r.xbet", "r.eps.0")}
+
+    r = subprocess.run(base + ["--chain-length", "9", "--restart"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RESTART: iteration_to_restart_from = 3" in r.stdout and "will restart from iteration: 4" in r.stdout
+    for p, raw in first.items():  # the failed job's files stay untouched (:1206)
+        assert open(out + "/" + p, "rb").read() == raw
+
+    # the oracle, restored from the same dump files the way init_from_restart reads them
+    csv3 = [float(x) for x in open(out + "/r.csv").read().splitlines()[3].split(",")]
+    assert csv3[0] == 3 and csv3[1] == 1
+    sigmaG, sigmaE, pi = csv3[2:3], csv3[3], csv3[8:12]
+    it_e, eps = _dump(out + "/r.eps.0", np.float64)
+    it_m, mrk = _dump(out + "/r.mrk.0", np.int32)
+    it_g, gam = _dump(out + "/r.gam.0", np.float64)
+    it_x, xiv = _dump(out + "/r.xiv.0", np.int32)
+    assert (it_e, it_m, it_g, it_x) == (3, 3, 3, 3) and eps.shape == (N,) and sorted(mrk) == list(range(M))
+    xb, xc = open(out + "/r.xbet", "rb").read(), open(out + "/r.xcpn", "rb").read()
+    assert struct.unpack("<II", xb[:8]) == (M, 3) and struct.unpack("<II", xc[:8]) == (M, 3)
+    mus = open(out + "/r.mus.0", "rb").read()
+    k, mu = struct.unpack("<Id", mus[36:48])
+    assert k == 3
+    ref = orc.Chain(oracle, synth.pack_bed_columns(geno), N, y, seed=12345)
+    ref.set_covariates(X)
+    ref.restore(3, sigmaE, mu, sigmaG, pi, np.frombuffer(xb[8:], dtype=np.float64), np.frombuffer(xc[8:], dtype=np.int32), eps, mrk,
+                words.astype(np.uint32), gamma=gam, xI=xiv)
+    its, betas = _read_bet(out + "/r_rs.bet", M, np.float64)
+    _, comps = _read_bet(out + "/r_rs.cpn", M, np.int32)
+    csv = open(out + "/r_rs.csv").read().splitlines()
+    assert its == [4, 5, 6, 7, 8] and len(csv) == 5
+    for k, it in enumerate(its):
+        ref.iterate()
+        assert np.array_equal(comps[k], ref.arr("components")) and close(betas[k], ref.arr("beta"))
+        got, want = [float(x) for x in csv[k].split(",")], [float(x) for x in ref.csv_line(it).split(",")]
+        assert close(got, want, 1e-9)
+    it_e2, eps2 = _dump(out + "/r_rs.eps.0", np.float64)
+    assert it_e2 == 6 and os.path.exists(out + "/r_rs.rng.0")
+    # --ignore-xfiles reads the same state out of the .bet/.cpn history
+    r = subprocess.run(base + ["--chain-length", "6", "--restart", "--ignore-xfiles"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    its2, betas2 = _read_bet(out + "/r_rs.bet", M, np.float64)
+    assert its2 == [4, 5] and np.array_equal(betas2, betas[:2])
+
+
+def test_cli_restart_refuses_bad_inputs(tmp_path):
+    M, N = 20, 64
+    geno = synth.make_genotypes(M, N, seed=1)
+    y, _ = synth.make_phenotype(geno, seed=2)
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, synth.pack_bed_columns(geno), N, y=y)
+    base = [EXE, "--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--mcmc-out-dir", out, "--mcmc-out-name", "r",
+            "--number-individuals", str(N), "--number-markers", str(M), "--thin", "1", "--seed", "8"]
+    r = subprocess.run(base + ["--chain-length", "3", "--save", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0
+    r = subprocess.run(base + ["--chain-length", "9", "--save", "5", "--restart"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "restarting a chain from iteration 0" in r.stderr  # only it 0 is a multiple of --save
+    r = subprocess.run(base + ["--chain-length", "4", "--save", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0
+    with open(out + "/r.mrk.0", "r+b") as f:  # a dump from another iteration is refused (data.cpp:53-56)
+        f.write(struct.pack("<I", 1))
+    r = subprocess.run(base + ["--chain-length", "9", "--save", "2", "--restart"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "Mismatch between expected and read" in r.stderr
