@@ -94,6 +94,27 @@ def make_phenotype(geno, seed=43, h2=0.5, causal_frac=0.01):
     return gval + e, beta
 
 
+def make_survival(geno, seed=44, h2=0.5, causal_frac=0.01, mu=3.0, alpha=4.0, censor_rate=0.3):
+    """Weibull log-time phenotype for BayesW: y = mu + X beta + w / alpha with w the log of a
+    unit exponential shifted by Euler's constant (mean 0), so exp(alpha * (y - mu - X beta) - gamma_E)
+    is unit exponential as the model assumes (src/BayesW.cpp:42,1457-1459).  Returns (y, failure, beta);
+    failure = 1 for an observed event, 0 for a censored one (censored times are shortened)."""
+    M, N = geno.shape
+    rng = np.random.default_rng(seed)
+    m_causal = max(1, int(round(M * causal_frac)))
+    causal = rng.choice(M, size=m_causal, replace=False)
+    var_e = np.pi ** 2 / (6.0 * alpha ** 2)
+    var_g = var_e * h2 / (1.0 - h2)
+    beta = np.zeros(M)
+    beta[causal] = rng.normal(0.0, np.sqrt(var_g / m_causal), size=m_causal)
+    gval = standardize(geno[causal]) @ beta[causal]
+    w = np.log(rng.exponential(1.0, size=N)) + 0.577215664901532
+    y = mu + gval + w / alpha
+    fail = (rng.random(N) >= censor_rate).astype(np.int32)
+    y = np.where(fail == 1, y, y - rng.exponential(0.2, size=N))
+    return y, fail, beta
+
+
 def write_plink(prefix, bed, N, y=None, na_rows=()):
     """Write <prefix>.bed/.fam/.bim (+ .phen) for a packed (M, ceil(N/4)) array."""
     M = bed.shape[0]

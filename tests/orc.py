@@ -14,7 +14,7 @@ class OrcMt(C.Structure):
 
 def _build():
     lib = os.path.join(ORACLE_DIR, "liboracle.so")
-    src = [os.path.join(ORACLE_DIR, f) for f in ("orc_gibbs.cpp", "orc_rng.h", "zig_tables.h")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("orc_gibbs.cpp", "orc_bayesw.cpp", "orc_rng.h", "orc_ars.h", "zig_tables.h", "gh_tables.h")]
     if (not os.path.exists(lib)) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "--quiet", os.path.join(ORACLE_DIR, "liboracle.so")])
     return lib
@@ -193,4 +193,117 @@ class Chain:
     def csv_line(self, it):
         buf = C.create_string_buffer(50000)
         n = self.L.orc_chain_csv_line(self.h, it, buf, 50000)
+        return buf.raw[:n].decode()
+
+
+def _bind_bw(L):
+    if getattr(L, "_bw_bound", False):
+        return
+    dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    L.orc_bw_create.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, dp, dp, C.c_int, C.c_int, ip, dp, C.c_uint32, C.c_int, C.c_int]
+    L.orc_bw_create.restype = vp
+    L.orc_bw_destroy.argtypes = [vp]
+    L.orc_bw_set_arms.argtypes = [vp, vp]
+    L.orc_bw_set_covariates.argtypes = [vp, dp, C.c_int]
+    L.orc_bw_reseed_ars.argtypes = [vp, C.c_uint32]
+    L.orc_bw_iterate.argtypes = [vp]
+    L.orc_bw_quad_supported.argtypes = [C.c_int]
+    for f in ("beta", "eps", "vi", "sigmaG", "pi", "mave", "msd", "sum_failure", "gamma"):
+        getattr(L, "orc_bw_" + f).argtypes = [vp]
+        getattr(L, "orc_bw_" + f).restype = dp
+    for f in ("components", "order", "cass", "m0"):
+        getattr(L, "orc_bw_" + f).argtypes = [vp]
+        getattr(L, "orc_bw_" + f).restype = ip
+    L.orc_bw_xI.argtypes = [vp]
+    L.orc_bw_xI.restype = C.POINTER(C.c_uint32)
+    for f in ("mu", "alpha"):
+        getattr(L, "orc_bw_" + f).argtypes = [vp]
+        getattr(L, "orc_bw_" + f).restype = C.c_double
+    for f in ("last_nnz", "ars_evals"):
+        getattr(L, "orc_bw_" + f).argtypes = [vp]
+        getattr(L, "orc_bw_" + f).restype = C.c_long
+    L.orc_bw_rng.argtypes = [vp]
+    L.orc_bw_rng.restype = C.POINTER(OrcMt)
+    L.orc_bw_csv_line.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.orc_bw_beta_dens.argtypes = [C.c_double] * 10
+    L.orc_bw_beta_dens.restype = C.c_double
+    L.orc_bw_marginals.argtypes = [C.c_int, C.c_int, dp, dp] + [C.c_double] * 9 + [dp]
+    L._bw_bound = True
+
+
+REF_ARMS_SYMBOL = "_Z4armsPdiS_S_PFddPvES0_S_iiS_S_iS_S_iPi"  # arms(...) of src/BayesW_arms.cpp, compiled as C++
+
+
+def ref_arms_lib():
+    """oracle/_ref/libarms.so (the reference's own ARS sampler) or None."""
+    path = os.path.join(ORACLE_DIR, "_ref", "libarms.so")
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+class BwChain:
+    """Python face of the oracle's BayesW driver (libc rand() is process-global: run one chain at a time)."""
+
+    def __init__(self, L, bed, N, y, fail, groups=None, mS=None, seed=1222, shuffle=1, quad=9):
+        _bind_bw(L)
+        self.L = L
+        self.bed = np.ascontiguousarray(bed, dtype=np.uint8)
+        self.M, self.stride = self.bed.shape
+        self.N = N
+        if mS is None:
+            mS = np.array([[0.0, 0.001, 0.01]])
+        self.mS = np.ascontiguousarray(mS, dtype=np.float64)
+        self.G, self.K = self.mS.shape
+        self.groups = np.ascontiguousarray(groups if groups is not None else np.zeros(self.M), dtype=np.int32)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self.fail = np.ascontiguousarray(fail, dtype=np.float64)
+        self.C = 0
+        self.h = L.orc_bw_create(u8ptr(self.bed), self.stride, N, self.M, dptr(self.y), dptr(self.fail), self.G, self.K,
+                                 iptr(self.groups), dptr(self.mS), seed, shuffle, quad)
+
+    def __del__(self):
+        try:
+            self.L.orc_bw_destroy(self.h)
+        except Exception:
+            pass
+
+    def use_reference_arms(self, lib):
+        fn = getattr(lib, REF_ARMS_SYMBOL)
+        self.L.orc_bw_set_arms(self.h, C.cast(fn, C.c_void_p))
+
+    def set_covariates(self, X):
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.C = self.X.shape[1]
+        self.L.orc_bw_set_covariates(self.h, dptr(self.X), self.C)
+
+    def reseed_ars(self, seed):
+        self.L.orc_bw_reseed_ars(self.h, seed)
+
+    def iterate(self):
+        err = self.L.orc_bw_iterate(self.h)
+        if err:
+            raise RuntimeError("ARS error code %d" % err)
+
+    def arr(self, name):
+        n = {"beta": self.M, "eps": self.N, "vi": self.N, "sigmaG": self.G, "pi": self.G * self.K, "mave": self.M, "msd": self.M,
+             "sum_failure": self.M, "gamma": self.C, "components": self.M, "order": self.M, "cass": self.G * self.K, "m0": self.G}[name]
+        return np.ctypeslib.as_array(getattr(self.L, "orc_bw_" + name)(self.h), shape=(n,))
+
+    @property
+    def mu(self):
+        return self.L.orc_bw_mu(self.h)
+
+    @property
+    def alpha(self):
+        return self.L.orc_bw_alpha(self.h)
+
+    def last_nnz(self):
+        return self.L.orc_bw_last_nnz(self.h)
+
+    def ars_evals(self):
+        return self.L.orc_bw_ars_evals(self.h)
+
+    def csv_line(self, it):
+        buf = C.create_string_buffer(50000)
+        n = self.L.orc_bw_csv_line(self.h, it, buf, 50000)
         return buf.raw[:n].decode()
