@@ -22,6 +22,12 @@ ABI_SYMBOLS = [
     "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
+    # BayesW
+    "hgibbs_grand_seed", "hgibbs_grand_next", "hgibbs_ars_sample", "hgibbs_w_init", "hgibbs_w_marker_stats", "hgibbs_w_set_model",
+    "hgibbs_w_reduce", "hgibbs_w_refresh_vi", "hgibbs_w_get_vi", "hgibbs_w_marker_sums", "hgibbs_w_sweep", "hgibbs_w_last_sweep_stats",
+    "hgibbs_w_get_beta", "hgibbs_w_set_beta", "hydraw_chain_create", "hydraw_chain_destroy", "hydraw_chain_set_covariates",
+    "hydraw_chain_reseed_ars", "hydraw_chain_iterate", "hydraw_chain_state", "hydraw_chain_gamma", "hydraw_chain_order",
+    "hydraw_chain_last_nnz", "hydraw_chain_csv_line",
 ]
 
 
@@ -39,6 +45,23 @@ class RestartState(C.Structure):
                 ("sigmaG", C.POINTER(C.c_double)), ("estPi", C.POINTER(C.c_double)), ("beta", C.POINTER(C.c_double)),
                 ("components", C.POINTER(C.c_int32)), ("eps", C.POINTER(C.c_double)), ("order", C.POINTER(C.c_int32)),
                 ("gamma", C.POINTER(C.c_double)), ("xI", C.POINTER(C.c_int32)), ("rng", RngState)]
+
+
+class GrandState(C.Structure):
+    _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int32), ("b", C.c_int32)]
+
+
+class WSweepStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("ars_draws", C.c_uint64), ("ars_evals", C.c_uint64),
+                ("device_ms", C.c_double)]
+
+
+class WModelDesc(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("shuffle", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
+                ("groups", C.POINTER(C.c_int32)), ("mS", C.POINTER(C.c_double)), ("quad_points", C.c_int32)]
+
+
+LOGDENS_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
 
 
 class ModelDesc(C.Structure):
@@ -109,6 +132,35 @@ def lib():
     L.hydra_chain_order.argtypes = [vp]
     L.hydra_chain_order.restype = ip
     L.hydra_chain_last_nnz.argtypes = [vp]
+    gp = C.POINTER(GrandState)
+    L.hgibbs_grand_seed.argtypes = [gp, C.c_uint32]
+    L.hgibbs_grand_seed.restype = None
+    L.hgibbs_grand_next.argtypes = [gp]
+    L.hgibbs_grand_next.restype = C.c_int32
+    L.hgibbs_ars_sample.argtypes = [dp, C.c_double, C.c_double, LOGDENS_FN, C.c_void_p, gp, dp, ip]
+    L.hgibbs_w_init.argtypes = [vp, ip]
+    L.hgibbs_w_marker_stats.argtypes = [vp, dp, dp, dp]
+    L.hgibbs_w_set_model.argtypes = [vp, C.c_int, C.c_int, ip, dp, C.c_int]
+    L.hgibbs_w_reduce.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp]
+    L.hgibbs_w_refresh_vi.argtypes = [vp, C.c_double]
+    L.hgibbs_w_get_vi.argtypes = [vp, dp, dp]
+    L.hgibbs_w_marker_sums.argtypes = [vp, C.c_uint32, C.c_double, C.c_double, dp, dp, dp]
+    L.hgibbs_w_sweep.argtypes = [vp, ip, C.c_double, dp, dp, C.c_double, C.POINTER(RngState), gp, ip, dp, u64p]
+    L.hgibbs_w_last_sweep_stats.argtypes = [vp, C.POINTER(WSweepStats)]
+    L.hgibbs_w_get_beta.argtypes = [vp, dp, ip]
+    L.hgibbs_w_set_beta.argtypes = [vp, dp, ip]
+    L.hydraw_chain_create.argtypes = [vp, C.POINTER(WModelDesc), dp, ip, C.POINTER(vp)]
+    L.hydraw_chain_destroy.argtypes = [vp]
+    L.hydraw_chain_set_covariates.argtypes = [vp, dp, C.c_int]
+    L.hydraw_chain_reseed_ars.argtypes = [vp, C.c_uint32]
+    L.hydraw_chain_iterate.argtypes = [vp]
+    L.hydraw_chain_state.argtypes = [vp, dp, dp, dp, dp, ip, ip, C.POINTER(RngState), gp]
+    L.hydraw_chain_gamma.argtypes = [vp, dp, ip]
+    L.hydraw_chain_order.argtypes = [vp]
+    L.hydraw_chain_order.restype = C.POINTER(C.c_int32)
+    L.hydraw_chain_last_nnz.argtypes = [vp]
+    L.hydraw_chain_last_nnz.restype = C.c_uint64
+    L.hydraw_chain_csv_line.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
     L.hydra_chain_last_nnz.restype = C.c_uint64
     _lib = L
     return L
@@ -248,6 +300,11 @@ class Device:
     def add_scalar(self, c):
         check(self.L.hgibbs_add_scalar(self.h, c))
 
+    def set_covariates(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.shape[0] == self.n_local
+        check(self.L.hgibbs_set_covariates(self.h, _dp(X), X.shape[1]))
+
     def update_marker(self, marker, dbeta):
         check(self.L.hgibbs_update_marker(self.h, marker, dbeta))
 
@@ -382,4 +439,137 @@ class Chain:
     def csv_line(self, it):
         buf = C.create_string_buffer(50000)
         n = self.L.hydra_chain_csv_line(self.h, it, buf, 50000)
+        return buf.raw[:n].decode()
+
+
+def ars_sample(logdens, xinit, xl, xr, grand):
+    """One ARS draw from exp(logdens) on [xl, xr] (host code; no GPU involved). Returns (err, x, neval)."""
+    L = lib()
+    cb = LOGDENS_FN(lambda x, _d: logdens(x))
+    xi = np.ascontiguousarray(xinit, dtype=np.float64)
+    out, ne = C.c_double(0.0), C.c_int(0)
+    err = L.hgibbs_ars_sample(_dp(xi), xl, xr, cb, None, C.byref(grand), C.byref(out), C.byref(ne))
+    return err, out.value, ne.value
+
+
+class BwOps:
+    """BayesW operators of a loaded Device (hgibbs_w_*)."""
+
+    def __init__(self, dev, failure):
+        self.dev, self.L = dev, dev.L
+        self.fail = np.ascontiguousarray(failure, dtype=np.int32)
+        assert self.fail.shape[0] == dev.n_global
+        check(self.L.hgibbs_w_init(dev.h, _ip(self.fail)))
+
+    def marker_stats(self):
+        M = self.dev.M
+        a, b, c = np.zeros(M), np.zeros(M), np.zeros(M)
+        check(self.L.hgibbs_w_marker_stats(self.dev.h, _dp(a), _dp(b), _dp(c)))
+        return a, b, c
+
+    def set_model(self, mS, groups=None, quad=9):
+        mS = np.ascontiguousarray(mS, dtype=np.float64)
+        self.G, self.K = mS.shape
+        g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        check(self.L.hgibbs_w_set_model(self.dev.h, self.G, self.K, _ip(g) if g is not None else None, _dp(mS), quad))
+
+    def reduce(self, kind, col=0, p0=0.0, p1=0.0, p2=0.0):
+        out = C.c_double()
+        check(self.L.hgibbs_w_reduce(self.dev.h, kind, col, p0, p1, p2, C.byref(out)))
+        return out.value
+
+    def refresh_vi(self, alpha):
+        check(self.L.hgibbs_w_refresh_vi(self.dev.h, alpha))
+
+    def get_vi(self):
+        v, s = np.zeros(self.dev.n_local), C.c_double()
+        check(self.L.hgibbs_w_get_vi(self.dev.h, _dp(v), C.byref(s)))
+        return v, s.value
+
+    def marker_sums(self, marker, beta_old, alpha):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(self.L.hgibbs_w_marker_sums(self.dev.h, marker, beta_old, alpha, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def get_beta(self):
+        b, c = np.zeros(self.dev.M), np.zeros(self.dev.M, dtype=np.int32)
+        check(self.L.hgibbs_w_get_beta(self.dev.h, _dp(b), _ip(c)))
+        return b, c
+
+    def sweep_stats(self):
+        st = WSweepStats()
+        check(self.L.hgibbs_w_last_sweep_stats(self.dev.h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+
+class BwChain:
+    """hydraw_chain_t: the runMpiGibbs_bW body on top of a loaded Device."""
+
+    def __init__(self, dev, y, failure, mS=None, groups=None, seed=1222, shuffle=1, quad=9):
+        self.dev, self.L = dev, dev.L
+        if mS is None:
+            mS = np.array([[0.0, 0.001, 0.01]])
+        self.mS = np.ascontiguousarray(mS, dtype=np.float64)
+        self.G, self.K = self.mS.shape
+        self.groups = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self.fail = np.ascontiguousarray(failure, dtype=np.int32)
+        assert y.shape[0] == dev.n_global and self.fail.shape[0] == dev.n_global
+        d = WModelDesc(seed, shuffle, self.G, self.K, _ip(self.groups) if self.groups is not None else None, _dp(self.mS), quad)
+        self.h = C.c_void_p()
+        self.C = 0
+        check(self.L.hydraw_chain_create(dev.h, C.byref(d), _dp(y), _ip(self.fail), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.hydraw_chain_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_covariates(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.C = X.shape[1]
+        check(self.L.hydraw_chain_set_covariates(self.h, _dp(X), self.C))
+
+    def reseed_ars(self, seed):
+        check(self.L.hydraw_chain_reseed_ars(self.h, seed))
+
+    def iterate(self):
+        check(self.L.hydraw_chain_iterate(self.h))
+
+    def state(self):
+        G, K = self.G, self.K
+        mu, alpha = C.c_double(), C.c_double()
+        sG, pi = np.zeros(G), np.zeros((G, K))
+        m0, cass = np.zeros(G, dtype=np.int32), np.zeros((G, K), dtype=np.int32)
+        rng, gr = RngState(), GrandState()
+        check(self.L.hydraw_chain_state(self.h, C.byref(mu), C.byref(alpha), _dp(sG), _dp(pi), _ip(m0), _ip(cass), C.byref(rng), C.byref(gr)))
+        return {"mu": mu.value, "alpha": alpha.value, "sigmaG": sG, "pi": pi, "m0": m0, "cass": cass,
+                "rng_x": np.array(rng.x, dtype=np.uint32), "rng_idx": int(rng.idx), "grand": gr}
+
+    def gamma(self):
+        g, xi = np.zeros(self.C), np.zeros(self.C, dtype=np.int32)
+        check(self.L.hydraw_chain_gamma(self.h, _dp(g), _ip(xi)))
+        return g, xi
+
+    def beta(self):
+        b, c = np.zeros(self.dev.M), np.zeros(self.dev.M, dtype=np.int32)
+        check(self.L.hgibbs_w_get_beta(self.dev.h, _dp(b), _ip(c)))
+        return b, c
+
+    def order(self):
+        return np.ctypeslib.as_array(self.L.hydraw_chain_order(self.h), shape=(self.dev.M,)).copy()
+
+    def last_nnz(self):
+        return int(self.L.hydraw_chain_last_nnz(self.h))
+
+    def sweep_stats(self):
+        st = WSweepStats()
+        check(self.L.hgibbs_w_last_sweep_stats(self.dev.h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def csv_line(self, it):
+        buf = C.create_string_buffer(50000)
+        n = self.L.hydraw_chain_csv_line(self.h, it, buf, 50000)
         return buf.raw[:n].decode()

@@ -1,0 +1,832 @@
+// hg_bayesw.hip.h -- BayesW (Weibull survival) operators behind include/hgibbs.h, for gfx950.
+// Included at the end of hgibbs.hip: shares the handle, the packed genotype shard, the permuted
+// residual layout and the covariate columns with the BayesR path.
+//
+// What the reference does per marker (src/BayesW.cpp:1484-1622): three sums of
+// vi = exp(alpha*eps - EuMasc) masked by genotype, adaptive Gauss-Hermite marginal likelihoods
+// of the K-1 slab components, a categorical walk with one Boost uniform, and -- if a slab is
+// chosen -- one adaptive-rejection draw of the effect on scalars only; a non-zero change of the
+// effect updates eps and refreshes vi.  Here:
+//   k_bw_sums     one launch = the masked sums of up to 256 markers against the SAME vi (valid
+//                 until the first effect changes), 8 columns per workgroup per pass over vi;
+//                 the last-arriving workgroup reduces in fixed order, evaluates the quadrature
+//                 for every column in parallel, walks the components with the column's uniform
+//                 and reports the first column that is an event (slab chosen, or an effect that
+//                 was non-zero).  A marker whose effect was non-zero rides along as one extra
+//                 column group computing exp(alpha*(eps + effect*x) - EuMasc) on the fly.
+//   k_bw_refresh  eps += delta(genotype) for the event's marker fused with vi = exp(alpha*eps - EuMasc)
+//                 and the block partials of sum(vi).
+//   k_bw_reduce   the N-length sums inside the log densities of mu, alpha and the covariates.
+// The uniforms are one u32 per marker in sweep order, so they are generated up front; the ARS
+// draw runs on the host between launches (hg_ars.h), on scalars the launch hands back.
+#pragma once
+
+#include "hg_ars.h"
+#include "hg_bayesw_math.h"
+#include "hg_gh_tables.h"
+
+namespace {
+
+constexpr uint32_t BW_ROWS = 2 * MAX_BATCH + 4; // per slice: (vi_1, vi_2) per column + (sum, vi_1, vi_2) of the shifted column
+
+struct BwResult {
+    uint32_t event; // index in the batch of the first event, == columns in the batch if none
+    int32_t k;      // component picked for the event column
+    double vi_sum, vi_1, vi_2; // its masked sums
+};
+
+struct BwBatchParams {
+    const uint8_t* bed;
+    uint64_t stride;
+    const double* eps;
+    const double* vi;
+    uint32_t n_pad, n_local;
+    const int32_t* markers; // device: order + cursor
+    uint32_t ncols;         // columns whose effect is zero
+    int32_t shifted_marker; // -1, or the marker right after them whose effect is not zero
+    double dv[3];           // what eps gains per genotype when that effect is taken out
+    double alpha;
+    uint32_t slices;
+    double* partials; // [slice][BW_ROWS]
+    uint32_t* ticket;
+    // quadrature + walk
+    const double* p_unif; // device: uniforms + cursor
+    const double *mave, *sd, *sumfail;
+    const int32_t* groups;
+    const double *cva, *pi, *sigmaG;
+    int K;
+    const double *ghx, *ghw;
+    int quad;
+    const double* vi_sum;
+    BwResult* result;
+    int32_t* picks;   // MAX_BATCH + 1
+    double* col_sums; // (MAX_BATCH + 1) x 3, for the single-marker operator and tests
+};
+
+// eps (+ delta of one marker) -> eps, vi; per-block partial of sum(vi).  marker < 0: refresh only.
+__global__ __launch_bounds__(BLOCK) void k_bw_refresh(const uint8_t* __restrict__ bed, uint64_t stride, int32_t marker, double v0, double v1,
+                                                      double v2, double* eps, double* vi, double alpha, uint32_t n_local, double* partial)
+{
+    __shared__ double sh[BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT], v[IPT];
+    load_eps16(eps, tile, lane, e);
+    if (marker >= 0) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(bed + (size_t)marker * stride + ((size_t)tile << 8) + (lane << 2));
+        apply_update16(w, v0, v1, v2, e);
+        store_eps16(eps, tile, lane, e);
+    }
+    const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        v[k] = (i0 + k < n_local) ? exp(alpha * e[k] - bw::EULER) : 0.0;
+        s += v[k];
+    }
+    store_eps16(vi, tile, lane, v);
+    s = wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) t += sh[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// N-length sums inside the scalar log densities.  kind 0: mu_dens (src/BayesW.cpp:77-88) with
+// used = eps + p0:  sum exp((used - p1)*p2 - EuMasc);  kind 1: alpha_dens (:132-142) sum exp(eps*p0 - EuMasc);
+// kind 2: gamma_dens (:118-129) with used = eps + x*p0: sum exp((used - x*p1)*p2 - EuMasc);
+// kind 3: sum eps*failure (:139).
+__global__ __launch_bounds__(BLOCK) void k_bw_reduce(const double* __restrict__ eps, const double* __restrict__ x,
+                                                     const uint32_t* __restrict__ failspread, int kind, double p0, double p1, double p2,
+                                                     uint32_t n_local, double* partial)
+{
+    __shared__ double sh[BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT], xv[IPT];
+    load_eps16(eps, tile, lane, e);
+    if (kind == 2) load_eps16(x, tile, lane, xv);
+    const uint32_t fs = (kind == 3) ? failspread[(tile << 6) + lane] : 0u;
+    const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        if (i0 + k >= n_local) continue;
+        double t;
+        if (kind == 0) t = exp(((e[k] + p0) - p1) * p2 - bw::EULER);
+        else if (kind == 1) t = exp((e[k] * p0) - bw::EULER);
+        else if (kind == 2) t = exp((((e[k] + xv[k] * p0) - xv[k] * p1) * p2) - bw::EULER);
+        else t = ((fs >> (2 * k)) & 1u) ? e[k] : 0.0;
+        s += t;
+    }
+    s = wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) t += sh[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// per marker: sum of the failure indicator over genotype 1 / genotype 2 (src/BayesW.cpp:1221-1228)
+__global__ __launch_bounds__(BLOCK) void k_bw_fail_counts(const uint8_t* __restrict__ bed, uint64_t stride, const uint32_t* __restrict__ failspread,
+                                                          uint32_t ndw, unsigned long long* out)
+{
+    __shared__ unsigned long long sh[2][BLOCK_WAVES];
+    const uint32_t marker = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(bed + (size_t)marker * stride);
+    unsigned long long c1 = 0, c2 = 0;
+    for (uint32_t i = threadIdx.x; i < ndw; i += BLOCK) {
+        uint32_t m1, m2, mm;
+        code_masks(col[i], m1, m2, mm);
+        const uint32_t fs = failspread[i];
+        c1 += (unsigned)__popc(m1 & fs);
+        c2 += (unsigned)__popc(m2 & fs);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c1 += __shfl_down(c1, off);
+        c2 += __shfl_down(c2, off);
+    }
+    if (lane == 0) {
+        sh[0][wave] = c1;
+        sh[1][wave] = c2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < BLOCK_WAVES; ++w) {
+            a += sh[0][w];
+            b += sh[1][w];
+        }
+        out[2 * marker] = a;
+        out[2 * marker + 1] = b;
+    }
+}
+
+// failure indicator of 16 consecutive individuals -> bits 0,2,4,...,30 (the genotype bit planes' positions)
+__global__ void k_bw_failspread(const int32_t* __restrict__ fail, uint32_t n_local, uint32_t ndw, uint32_t* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndw) return;
+    uint32_t m = 0;
+    for (int s = 0; s < 16; ++s) {
+        const uint32_t ind = i * 16 + s;
+        if (ind < n_local && fail[ind] != 0) m |= 1u << (2 * s);
+    }
+    out[i] = m;
+}
+
+// the three masked sums of ONE marker, per-block partials (the single-marker operator)
+__global__ __launch_bounds__(BLOCK) void k_bw_marker_sums(const uint8_t* __restrict__ bed, uint64_t stride, uint32_t marker,
+                                                          const double* __restrict__ eps, const double* __restrict__ vi, bool shifted, double d0,
+                                                          double d1, double d2, double alpha, uint32_t n_local, double* partial)
+{
+    __shared__ double sh[3][BLOCK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
+    double e[IPT];
+    load_eps16(shifted ? eps : vi, tile, lane, e);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(bed + (size_t)marker * stride + ((size_t)tile << 8) + (lane << 2));
+    const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
+    double s = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const uint32_t c = (w >> (2 * k)) & 3u;
+        double t = e[k];
+        if (shifted) {
+            const double de = (c == 3u) ? d0 : ((c == 2u) ? d1 : ((c == 0u) ? d2 : 0.0));
+            t = (i0 + k < n_local) ? exp(alpha * (e[k] + de) - bw::EULER) : 0.0;
+        }
+        s += t;
+        s1 += (c == 2u) ? t : 0.0;
+        s2 += (c == 0u) ? t : 0.0;
+    }
+    s = wave_sum(s);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        sh[0][wave] = s;
+        sh[1][wave] = s1;
+        sh[2][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int w2 = 0; w2 < BLOCK_WAVES; ++w2) t += sh[threadIdx.x][w2];
+        partial[3 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
+template <int CPG>
+__global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
+{
+    __shared__ double wpart[BLOCK_WAVES][2 * CPG + 4];
+    __shared__ uint32_t s_flag[2]; // [0] last arriver, [1] first event
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ngn = (p.ncols + CPG - 1) / CPG;
+    const uint32_t S = p.slices;
+    const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
+    const uint32_t ntg = p.n_pad / BLOCK_IND;
+    const uint32_t nb = p.ncols + (p.shifted_marker >= 0 ? 1u : 0u);
+
+    if (group < ngn) {
+        const uint32_t c0 = group * CPG;
+        const uint32_t ncol = (c0 + CPG <= p.ncols) ? CPG : p.ncols - c0;
+        const uint8_t* colp[CPG];
+        double a1[CPG], a2[CPG];
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const uint32_t j = (c0 + c < p.ncols) ? c0 + c : p.ncols - 1;
+            colp[c] = p.bed + (size_t)p.markers[j] * p.stride + (lane << 2);
+            a1[c] = a2[c] = 0.0;
+        }
+        for (uint32_t tg = slice; tg < ntg; tg += S) {
+            const uint32_t tile = tg * BLOCK_WAVES + wave;
+            double e[IPT];
+            load_eps16(p.vi, tile, lane, e);
+            uint32_t m1[CPG], m2[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                uint32_t mm;
+                code_masks(*reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8)), m1[c], m2[c], mm);
+            }
+            // weight 0/1 times vi is exact: one rounding per add, slots in increasing order
+#pragma unroll
+            for (int c = 0; c < CPG; c += 4) {
+                fma_slots4(m1[c], m1[c + 1], m1[c + 2], m1[c + 3], e, a1[c], a1[c + 1], a1[c + 2], a1[c + 3], std::make_integer_sequence<int, IPT>{});
+                fma_slots4(m2[c], m2[c + 1], m2[c + 2], m2[c + 3], e, a2[c], a2[c + 1], a2[c + 2], a2[c + 3], std::make_integer_sequence<int, IPT>{});
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
+            if (lane == 0) {
+                wpart[wave][2 * c] = t1;
+                wpart[wave][2 * c + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < (int)(2 * ncol)) {
+            double v = wpart[0][tid];
+            v += wpart[1][tid];
+            v += wpart[2][tid];
+            v += wpart[3][tid];
+            __hip_atomic_store(p.partials + (size_t)slice * BW_ROWS + 2 * c0 + tid, v, HG_RLX_AGENT);
+        }
+    } else {
+        // the marker whose effect is not zero: vi as it would be with that effect taken out (src/BayesW.cpp:1499-1516)
+        const uint8_t* colp = p.bed + (size_t)p.shifted_marker * p.stride + (lane << 2);
+        double s = 0.0, s1 = 0.0, s2 = 0.0;
+        for (uint32_t tg = slice; tg < ntg; tg += S) {
+            const uint32_t tile = tg * BLOCK_WAVES + wave;
+            double e[IPT];
+            load_eps16(p.eps, tile, lane, e);
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(colp + ((size_t)tile << 8));
+            const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const uint32_t c = (w >> (2 * k)) & 3u;
+                const double de = (c == 3u) ? p.dv[0] : ((c == 2u) ? p.dv[1] : ((c == 0u) ? p.dv[2] : 0.0));
+                const double t = (i0 + k < p.n_local) ? exp(p.alpha * (e[k] + de) - bw::EULER) : 0.0;
+                s += t;
+                s1 += (c == 2u) ? t : 0.0;
+                s2 += (c == 0u) ? t : 0.0;
+            }
+        }
+        s = wave_sum(s);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            wpart[wave][0] = s;
+            wpart[wave][1] = s1;
+            wpart[wave][2] = s2;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            double v = wpart[0][tid];
+            v += wpart[1][tid];
+            v += wpart[2][tid];
+            v += wpart[3][tid];
+            __hip_atomic_store(p.partials + (size_t)slice * BW_ROWS + 2 * MAX_BATCH + tid, v, HG_RLX_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
+        s_flag[0] = (t == gridDim.x - 1u) ? 1u : 0u;
+        s_flag[1] = nb;
+    }
+    __syncthreads();
+    if (!s_flag[0]) return;
+
+    // ---- last-arriving workgroup: fixed-order reduction, quadrature, walk ------------------------
+    if (tid == 0) __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
+    bool is_event = false;
+    int k = 0;
+    bw::MarkerSums sums{0.0, 0.0, 0.0};
+    if (tid < (int)nb) {
+        const bool shifted = (uint32_t)tid >= p.ncols;
+        const uint32_t r0 = shifted ? 2 * MAX_BATCH : 2 * (uint32_t)tid;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (uint32_t s = 0; s < S; ++s) {
+            const double* row = p.partials + (size_t)s * BW_ROWS + r0;
+            t0 += __hip_atomic_load(row, HG_RLX_AGENT);
+            t1 += __hip_atomic_load(row + 1, HG_RLX_AGENT);
+            if (shifted) t2 += __hip_atomic_load(row + 2, HG_RLX_AGENT);
+        }
+        if (shifted) sums = bw::MarkerSums{t0, t1, t2};
+        else sums = bw::MarkerSums{*p.vi_sum, t0, t1};
+        const int marker = shifted ? p.shifted_marker : p.markers[tid];
+        const int grp = p.groups[marker];
+        double ml[bw::MAX_K];
+        bw::marginals(p.quad, p.ghx, p.ghw, p.K, p.pi + (size_t)grp * p.K, p.cva + (size_t)grp * (p.K - 1), p.alpha, p.sigmaG[grp],
+                      p.sumfail[marker], sums, p.mave[marker], p.sd[marker], ml);
+        k = bw::pick_component(p.K, ml, p.p_unif[tid]);
+        is_event = shifted || k != 0;
+        p.picks[tid] = k;
+        if (p.col_sums) {
+            p.col_sums[3 * tid] = sums.vi_sum;
+            p.col_sums[3 * tid + 1] = sums.vi_1;
+            p.col_sums[3 * tid + 2] = sums.vi_2;
+        }
+        if (is_event) atomicMin(&s_flag[1], (uint32_t)tid);
+    }
+    __syncthreads();
+    const uint32_t ev = s_flag[1];
+    if (ev == nb) {
+        if (tid == 0) *p.result = BwResult{nb, 0, 0.0, 0.0, 0.0};
+    } else if ((uint32_t)tid == ev) {
+        *p.result = BwResult{ev, k, sums.vi_sum, sums.vi_1, sums.vi_2};
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct BwState {
+    double* vi = nullptr;
+    uint32_t* failspread = nullptr;
+    double* vi_sum = nullptr; // device scalar
+    double *d_mave = nullptr, *d_sd = nullptr, *d_sumfail = nullptr;
+    double *d_cva = nullptr, *d_pi = nullptr, *d_sigmaG = nullptr;
+    double *d_ghx = nullptr, *d_ghw = nullptr;
+    double* d_unif = nullptr;
+    double* partials = nullptr;
+    BwResult* d_result = nullptr;
+    BwResult* h_result = nullptr; // pinned
+    int32_t* d_picks = nullptr;
+    double* d_colsums = nullptr;
+    std::vector<double> mave, sd, sumfail, cva, beta;
+    std::vector<int32_t> comp, fail;
+    std::vector<double> unif;
+    double d_total = 0.0; // number of events (sum of the failure indicator)
+    int G = 0, K = 0, quad = 0;
+    bool have_tables = false, have_model = false;
+    hgibbs_w_sweep_stats stats{};
+};
+
+static void bw_free(BwState* b)
+{
+    if (!b) return;
+    void* ptrs[] = {b->vi, b->failspread, b->vi_sum, b->d_mave, b->d_sd, b->d_sumfail, b->d_cva, b->d_pi, b->d_sigmaG, b->d_ghx, b->d_ghw,
+                    b->d_unif, b->partials, b->d_result, b->d_picks, b->d_colsums};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->h_result) (void)hipHostFree(b->h_result);
+    delete b;
+}
+
+static int bw_need(hgibbs_ctx* h, const char* who, bool tables = false, bool model = false)
+{
+    if (!h || !h->bed) return fail("%s: load genotypes first", who);
+    if (!h->bw) return fail("%s: call hgibbs_w_init first", who);
+    if (h->nranks > 1) return fail("%s: BayesW runs on one GPU in this build (individuals are not sharded for it)", who);
+    if (tables && !h->bw->have_tables) return fail("%s: call hgibbs_w_marker_stats first", who);
+    if (model && !h->bw->have_model) return fail("%s: call hgibbs_w_set_model first", who);
+    return 0;
+}
+
+// sum of `nblk` block partials in h->scratch -> device scalar dst (fixed order)
+static int bw_final(hgibbs_ctx* h, uint32_t nblk, double* dst)
+{
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 1, dst);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host)
+{
+    if (!h || !h->bed || !failure_host) return fail("hgibbs_w_init: load genotypes first and pass the failure indicator");
+    if (h->nranks > 1) return fail("hgibbs_w_init: BayesW runs on one GPU in this build");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->bw) return fail("hgibbs_w_init: already initialised on this handle");
+    for (uint32_t i = 0; i < h->n_global; ++i)
+        if (failure_host[i] != 0 && failure_host[i] != 1) return fail("hgibbs_w_init: failure indicator of individual %u is %d, not 0/1", i, failure_host[i]);
+    BwState* b = new BwState();
+    h->bw = b;
+    b->fail.assign(failure_host, failure_host + h->n_global);
+    b->d_total = 0.0;
+    for (uint32_t i = 0; i < h->n_global; ++i) b->d_total += (double)failure_host[i];
+    const uint32_t ndw = h->n_pad / 16;
+    HIP_TRY(hipMalloc(&b->vi, (size_t)h->n_pad * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(b->vi, 0, (size_t)h->n_pad * sizeof(double), h->stream));
+    HIP_TRY(hipMalloc(&b->failspread, (size_t)ndw * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b->vi_sum, sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_mave, (size_t)h->M * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_sd, (size_t)h->M * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_sumfail, (size_t)h->M * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_unif, (size_t)h->M * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->partials, (size_t)S_CAP * BW_ROWS * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_result, sizeof(BwResult)));
+    HIP_TRY(hipHostMalloc(&b->h_result, sizeof(BwResult)));
+    HIP_TRY(hipMalloc(&b->d_picks, (MAX_BATCH + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&b->d_colsums, (size_t)(MAX_BATCH + 1) * 3 * sizeof(double)));
+    int32_t* d_fail = nullptr;
+    HIP_TRY(hipMalloc(&d_fail, (size_t)h->n_local * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(d_fail, failure_host + h->row_begin, (size_t)h->n_local * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    k_bw_failspread<<<(ndw + 255) / 256, 256, 0, h->stream>>>(d_fail, h->n_local, ndw, b->failspread);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(d_fail));
+    b->beta.assign(h->M, 0.0);
+    b->comp.assign(h->M, 0);
+    return 0;
+}
+
+/* src/BayesW.cpp:1201-1232: mave as in BayesR, sd = sqrt(sum of squares / (N-1)) (the standard
+ * deviation, not its inverse), sum_failure = (sum_i g_ij d_i - mave * sum_i d_i) / sd.  The counts
+ * are integer work on the device; the three tables are computed from them here, in the reference's
+ * expression order, and kept on both sides. */
+int hgibbs_w_marker_stats(hgibbs_t h, double* mave, double* sd, double* sum_failure)
+{
+    if (bw_need(h, "hgibbs_w_marker_stats")) return 1;
+    HIP_TRY(hipSetDevice(h->device));
+    BwState* b = h->bw;
+    if (!b->have_tables) {
+        if (compute_stats(h)) return 1;
+        const uint32_t M = h->M;
+        std::vector<unsigned long long> cnt((size_t)3 * M), fc((size_t)2 * M);
+        HIP_TRY(hipMemcpy(cnt.data(), h->counts, cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long* d_fc = nullptr;
+        HIP_TRY(hipMalloc(&d_fc, fc.size() * sizeof(unsigned long long)));
+        k_bw_fail_counts<<<M, BLOCK, 0, h->stream>>>(h->bed, h->stride, b->failspread, h->n_pad / 16, d_fc);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(fc.data(), d_fc, fc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(d_fc));
+        b->mave.resize(M);
+        b->sd.resize(M);
+        b->sumfail.resize(M);
+        const uint32_t Ntot = h->n_global;
+        const double dN = (double)Ntot;
+        for (uint32_t i = 0; i < M; ++i) {
+            const unsigned long long n1 = cnt[3 * (size_t)i], n2 = cnt[3 * (size_t)i + 1], nm = cnt[3 * (size_t)i + 2];
+            const double mv = ((double)n1 + 2.0 * (double)n2) / (dN - (double)nm);
+            const double tmp1 = (double)n1 * (1.0 - mv) * (1.0 - mv);
+            const double tmp2 = (double)n2 * (2.0 - mv) * (2.0 - mv);
+            const double tmp0 = (double)(Ntot - n1 - n2 - nm) * (0.0 - mv) * (0.0 - mv);
+            b->mave[i] = mv;
+            b->sd[i] = std::sqrt((tmp0 + tmp1 + tmp2) / (double)(Ntot - 1));
+            const int temp_sum = (int)(fc[2 * (size_t)i] + 2ull * fc[2 * (size_t)i + 1]);
+            b->sumfail[i] = ((double)temp_sum - mv * b->d_total) / b->sd[i];
+        }
+        HIP_TRY(hipMemcpy(b->d_mave, b->mave.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_sd, b->sd.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_sumfail, b->sumfail.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice));
+        b->have_tables = true;
+    }
+    if (mave) std::copy(b->mave.begin(), b->mave.end(), mave);
+    if (sd) std::copy(b->sd.begin(), b->sd.end(), sd);
+    if (sum_failure) std::copy(b->sumfail.begin(), b->sumfail.end(), sum_failure);
+    return 0;
+}
+
+int hgibbs_w_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const double* mS, int quad_points)
+{
+    if (bw_need(h, "hgibbs_w_set_model")) return 1;
+    if (G < 1 || K < 2 || !mS) return fail("hgibbs_w_set_model: need G >= 1, K >= 2 and the mixture table");
+    if (K > bw::MAX_K) return fail("hgibbs_w_set_model: K = %d components, at most %d", K, bw::MAX_K);
+    const double *X = nullptr, *W = nullptr;
+    if (!hg_gh_lookup(quad_points, &X, &W)) return fail("Possible number of quad_points = 3,5,7,9,11,13,15,17,25 (got %d)", quad_points);
+    HIP_TRY(hipSetDevice(h->device));
+    BwState* b = h->bw;
+    h->groups_host.assign(h->M, 0);
+    if (groups_host)
+        for (uint32_t i = 0; i < h->M; ++i) {
+            if (groups_host[i] < 0 || groups_host[i] >= G) return fail("hgibbs_w_set_model: marker %u in group %d outside [0,%d)", i, groups_host[i], G);
+            h->groups_host[i] = groups_host[i];
+        }
+    HIP_TRY(hipMemcpy(h->groups, h->groups_host.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice));
+    b->G = G;
+    b->K = K;
+    b->quad = quad_points;
+    b->cva.resize((size_t)G * (K - 1));
+    for (int g = 0; g < G; ++g)
+        for (int k = 1; k < K; ++k) {
+            if (!(mS[(size_t)g * K + k] > 0.0)) return fail("hgibbs_w_set_model: mixture value can only be strictly positive");
+            b->cva[(size_t)g * (K - 1) + (k - 1)] = mS[(size_t)g * K + k];
+        }
+    for (double** p : {&b->d_cva, &b->d_pi, &b->d_sigmaG, &b->d_ghx, &b->d_ghw})
+        if (*p) {
+            HIP_TRY(hipFree(*p));
+            *p = nullptr;
+        }
+    HIP_TRY(hipMalloc(&b->d_cva, b->cva.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_pi, (size_t)G * K * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_sigmaG, (size_t)G * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_ghx, (size_t)(quad_points - 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_ghw, (size_t)quad_points * sizeof(double)));
+    HIP_TRY(hipMemcpy(b->d_cva, b->cva.data(), b->cva.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_ghx, X, (size_t)(quad_points - 1) * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_ghw, W, (size_t)quad_points * sizeof(double), hipMemcpyHostToDevice));
+    b->have_model = true;
+    return 0;
+}
+
+int hgibbs_w_reduce(hgibbs_t h, int kind, int col, double p0, double p1, double p2, double* out)
+{
+    if (bw_need(h, "hgibbs_w_reduce")) return 1;
+    if (!out || kind < 0 || kind > 3) return fail("hgibbs_w_reduce: kind %d outside [0,3] or null out", kind);
+    if (kind == 2 && (!h->covX || col < 0 || col >= h->C)) return fail("hgibbs_w_reduce: covariate %d outside [0,%d)", col, h->C);
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblk = h->n_pad / BLOCK_IND;
+    k_bw_reduce<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], kind == 2 ? h->covX + (size_t)col * h->n_pad : nullptr, h->bw->failspread,
+                                               kind, p0, p1, p2, h->n_local, h->scratch);
+    if (bw_final(h, nblk, h->sums)) return 1;
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *out = h->scratch_host[0];
+    return 0;
+}
+
+int hgibbs_w_refresh_vi(hgibbs_t h, double alpha)
+{
+    if (bw_need(h, "hgibbs_w_refresh_vi")) return 1;
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblk = h->n_pad / BLOCK_IND;
+    k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, -1, 0.0, 0.0, 0.0, h->eps[h->eps_cur], h->bw->vi, alpha, h->n_local, h->scratch);
+    return bw_final(h, nblk, h->bw->vi_sum);
+}
+
+int hgibbs_w_get_vi(hgibbs_t h, double* vi_host, double* vi_sum)
+{
+    if (bw_need(h, "hgibbs_w_get_vi")) return 1;
+    HIP_TRY(hipSetDevice(h->device));
+    if (vi_host) {
+        double* tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, (size_t)h->n_local * sizeof(double)));
+        k_get_eps<<<(h->n_local + 255) / 256, 256, 0, h->stream>>>(h->bw->vi, tmp, h->n_local);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(vi_host, tmp, (size_t)h->n_local * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(tmp));
+    }
+    if (vi_sum) HIP_TRY(hipMemcpy(vi_sum, h->bw->vi_sum, sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hgibbs_w_get_beta(hgibbs_t h, double* beta, int32_t* components)
+{
+    if (bw_need(h, "hgibbs_w_get_beta")) return 1;
+    if (beta) std::copy(h->bw->beta.begin(), h->bw->beta.end(), beta);
+    if (components) std::copy(h->bw->comp.begin(), h->bw->comp.end(), components);
+    return 0;
+}
+
+int hgibbs_w_set_beta(hgibbs_t h, const double* beta, const int32_t* components)
+{
+    if (bw_need(h, "hgibbs_w_set_beta")) return 1;
+    if (beta) h->bw->beta.assign(beta, beta + h->M);
+    if (components) h->bw->comp.assign(components, components + h->M);
+    return 0;
+}
+
+void hgibbs_grand_seed(hgibbs_grand_state* st, uint32_t seed)
+{
+    static_assert(sizeof(hgibbs_grand_state) == sizeof(hg::GlibcRand), "layout");
+    reinterpret_cast<hg::GlibcRand*>(st)->seed(seed);
+}
+
+int32_t hgibbs_grand_next(hgibbs_grand_state* st) { return reinterpret_cast<hg::GlibcRand*>(st)->next(); }
+
+int hgibbs_ars_sample(const double* xinit4, double xl, double xr, double (*logdens)(double, void*), void* data, hgibbs_grand_state* rng,
+                      double* xsamp, int* neval)
+{
+    if (!xinit4 || !logdens || !rng || !xsamp) return fail("hgibbs_ars_sample: null argument");
+    struct F {
+        double (*f)(double, void*);
+        void* d;
+        double operator()(double x) { return f(x, d); }
+    } f{logdens, data};
+    struct U {
+        hg::GlibcRand* g;
+        double operator()() { return g->uniform(); }
+    } u{reinterpret_cast<hg::GlibcRand*>(rng)};
+    const double xi[4] = {xinit4[0], xinit4[1], xinit4[2], xinit4[3]};
+    hg::ars::Hull hull;
+    int ne = 0;
+    const int err = hg::ars::sample(xi, xl, xr, f, u, hull, *xsamp, ne);
+    if (neval) *neval = ne;
+    if (err) fail("hgibbs_ars_sample: error %d (1003 bounds, 1004 order, 2000 log density not concave)", err);
+    return err;
+}
+
+/* One pass over all markers, src/BayesW.cpp:1461-1622.  The effect/component vectors live on the
+ * host side of the handle (hgibbs_w_get_beta); eps and vi on the device.  rng: dist.rng, one
+ * uniform per marker; ars_rng: the libc rand() stream of the ARS draws. */
+int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const double* sigmaG, const double* pi, double sumSigmaG,
+                   hgibbs_rng_state* rng, hgibbs_grand_state* ars_rng, int32_t* cass_host, double* beta_sqnorm, uint64_t* nnz_updates)
+{
+    if (bw_need(h, "hgibbs_w_sweep", true, true)) return 1;
+    if (!order_host || !sigmaG || !pi || !rng || !ars_rng || !cass_host || !beta_sqnorm) return fail("hgibbs_w_sweep: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    BwState* b = h->bw;
+    const uint32_t M = h->M;
+    const int G = b->G, K = b->K;
+    for (uint32_t i = 0; i < M; ++i)
+        if (order_host[i] < 0 || (uint32_t)order_host[i] >= M) return fail("hgibbs_w_sweep: order[%u] = %d outside [0,%u)", i, order_host[i], M);
+
+    // one Boost uniform per marker, in sweep order (src/BayesW.cpp:1528)
+    {
+        hg::Mt gen{rng->x, rng->idx};
+        b->unif.resize(M);
+        for (uint32_t j = 0; j < M; ++j) b->unif[j] = hg::unif01(gen);
+        rng->idx = gen.idx;
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_unif, b->unif.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->order, order_host, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_pi, pi, (size_t)G * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_sigmaG, sigmaG, (size_t)G * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::fill(cass_host, cass_host + (size_t)G * K, 0);
+    std::fill(beta_sqnorm, beta_sqnorm + G, 0.0);
+
+    const uint32_t ntg = h->n_pad / BLOCK_IND, nblk = ntg;
+    const uint32_t batch_cap = std::min<uint32_t>(h->batch ? h->batch : MAX_BATCH, MAX_BATCH);
+    constexpr int CPG = 8;
+    uint64_t nnz = 0, launches = 0, ars_draws = 0, ars_evals = 0;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    uint32_t cursor = 0;
+    hg::GlibcRand* gr = reinterpret_cast<hg::GlibcRand*>(ars_rng);
+    while (cursor < M) {
+        // columns with a zero effect, then (if it comes within reach) the first marker whose effect is not zero
+        uint32_t ncols = 0;
+        int32_t shifted = -1;
+        while (cursor + ncols < M && ncols < batch_cap) {
+            const int32_t mk = order_host[cursor + ncols];
+            if (b->beta[mk] != 0.0) {
+                shifted = mk;
+                break;
+            }
+            ++ncols;
+        }
+        const uint32_t nb = ncols + (shifted >= 0 ? 1u : 0u);
+        BwBatchParams p{};
+        p.bed = h->bed;
+        p.stride = h->stride;
+        p.eps = h->eps[h->eps_cur];
+        p.vi = b->vi;
+        p.n_pad = h->n_pad;
+        p.n_local = h->n_local;
+        p.markers = h->order + cursor;
+        p.ncols = ncols;
+        p.shifted_marker = shifted;
+        if (shifted >= 0) {
+            double dv[3];
+            bw::delta_values(b->beta[shifted], b->mave[shifted], b->sd[shifted], dv);
+            p.dv[0] = dv[0];
+            p.dv[1] = dv[1];
+            p.dv[2] = dv[2];
+        }
+        p.alpha = alpha;
+        const uint32_t ngroups = (ncols + CPG - 1) / CPG + (shifted >= 0 ? 1u : 0u);
+        uint32_t S = h->slices ? h->slices : S_CAP;
+        S = std::min<uint32_t>(std::min<uint32_t>(S, S_CAP), ntg);
+        S = std::max<uint32_t>(1u, std::min<uint32_t>(S, 768u / ngroups));
+        p.slices = S;
+        p.partials = b->partials;
+        p.ticket = h->ticket;
+        p.p_unif = b->d_unif + cursor;
+        p.mave = b->d_mave;
+        p.sd = b->d_sd;
+        p.sumfail = b->d_sumfail;
+        p.groups = h->groups;
+        p.cva = b->d_cva;
+        p.pi = b->d_pi;
+        p.sigmaG = b->d_sigmaG;
+        p.K = K;
+        p.ghx = b->d_ghx;
+        p.ghw = b->d_ghw;
+        p.quad = b->quad;
+        p.vi_sum = b->vi_sum;
+        p.result = b->d_result;
+        p.picks = b->d_picks;
+        p.col_sums = h->debug_timing ? b->d_colsums : nullptr;
+        k_bw_sums<CPG><<<S * ngroups, BLOCK, 0, h->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        ++launches;
+        HIP_TRY(hipMemcpyAsync(b->h_result, b->d_result, sizeof(BwResult), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const BwResult r = *b->h_result;
+        if (r.event > nb) return fail("hgibbs_w_sweep: device reported event %u in a batch of %u", r.event, nb);
+        // markers before the event keep a zero effect (src/BayesW.cpp:1541-1546)
+        for (uint32_t t = 0; t < std::min(r.event, ncols); ++t) {
+            const int32_t mk = order_host[cursor + t];
+            cass_host[(size_t)h->groups_host[mk] * K] += 1;
+            b->comp[mk] = 0;
+        }
+        if (r.event == nb) {
+            cursor += nb;
+            continue;
+        }
+        const int32_t mk = order_host[cursor + r.event];
+        const int grp = h->groups_host[mk];
+        const double beta_old = b->beta[mk];
+        if (r.k < 0) return fail("hgibbs_w_sweep: marginal likelihoods of marker %d are not finite", mk);
+        double beta_new = 0.0;
+        if (r.k > 0) { // src/BayesW.cpp:1548-1590
+            bw::BetaLogDensity f{alpha, sigmaG[grp], b->sumfail[mk], b->sd[mk], b->mave[mk] / b->sd[mk], b->cva[(size_t)grp * (K - 1) + (r.k - 1)],
+                                 r.vi_sum - r.vi_1 - r.vi_2, r.vi_1, r.vi_2};
+            const double safe_limit = 2 * std::sqrt(sumSigmaG * f.mixture_value);
+            const double xinit[4] = {beta_old - safe_limit / 10, beta_old, beta_old + safe_limit / 20, beta_old + safe_limit / 10};
+            struct U {
+                hg::GlibcRand* g;
+                double operator()() { return g->uniform(); }
+            } u{gr};
+            hg::ars::Hull hull;
+            int ne = 0;
+            const int err = hg::ars::sample(xinit, beta_old - safe_limit, beta_old + safe_limit, f, u, hull, beta_new, ne);
+            ++ars_draws;
+            ars_evals += (uint64_t)ne;
+            if (err) return fail("Error code = %d (ARS on the effect of marker %d)", err, mk);
+            beta_sqnorm[grp] += beta_new * beta_new;
+        }
+        cass_host[(size_t)grp * K + r.k] += 1;
+        b->comp[mk] = r.k;
+        b->beta[mk] = beta_new;
+        const double deltaBeta = beta_old - beta_new;
+        if (deltaBeta != 0.0) { // src/BayesW.cpp:1606-1622, :1812, :1832-1834
+            double dv[3];
+            bw::delta_values(deltaBeta, b->mave[mk], b->sd[mk], dv);
+            k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, mk, dv[0], dv[1], dv[2], h->eps[h->eps_cur], b->vi, alpha, h->n_local,
+                                                        h->scratch);
+            if (bw_final(h, nblk, b->vi_sum)) return 1;
+            ++nnz;
+        }
+        cursor += r.event + 1;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (nnz_updates) *nnz_updates = nnz;
+    b->stats.launches = launches;
+    b->stats.nnz_updates = nnz;
+    b->stats.ars_draws = ars_draws;
+    b->stats.ars_evals = ars_evals;
+    b->stats.device_ms = ms;
+    return 0;
+}
+
+int hgibbs_w_last_sweep_stats(hgibbs_t h, hgibbs_w_sweep_stats* out)
+{
+    if (bw_need(h, "hgibbs_w_last_sweep_stats") || !out) return 1;
+    *out = h->bw->stats;
+    return 0;
+}
+
+/* the per-marker operator on its own: the three masked sums of marker j as the sweep would see them */
+int hgibbs_w_marker_sums(hgibbs_t h, uint32_t marker, double beta_old, double alpha, double* vi_sum, double* vi_1, double* vi_2)
+{
+    if (bw_need(h, "hgibbs_w_marker_sums", true)) return 1;
+    if (marker >= h->M) return fail("hgibbs_w_marker_sums: marker %u >= M %u", marker, h->M);
+    HIP_TRY(hipSetDevice(h->device));
+    BwState* b = h->bw;
+    const uint32_t ntg = h->n_pad / BLOCK_IND;
+    const uint32_t nblk = ntg;
+    // shifted form reads eps; plain form reads vi
+    double dv[3] = {0.0, 0.0, 0.0};
+    if (beta_old != 0.0) bw::delta_values(beta_old, b->mave[marker], b->sd[marker], dv);
+    double* part = h->scratch; // 3 rows per block
+    k_bw_marker_sums<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, marker, h->eps[h->eps_cur], b->vi, beta_old != 0.0, dv[0], dv[1], dv[2], alpha,
+                                       h->n_local, part);
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(part, nblk, 3, h->sums);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (vi_sum) *vi_sum = h->scratch_host[0];
+    if (vi_1) *vi_1 = h->scratch_host[1];
+    if (vi_2) *vi_2 = h->scratch_host[2];
+    return 0;
+}
+
+} // extern "C"

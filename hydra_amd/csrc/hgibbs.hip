@@ -51,8 +51,12 @@ extern "C" void hgibbs_set_error_(const char* msg) { g_err = msg; }
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+struct BwState; // BayesW side of the handle (hg_bayesw.hip.h)
+static void bw_free(BwState* b);
+
 struct hgibbs_ctx {
     int device = 0;
+    BwState* bw = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -524,6 +528,7 @@ int hgibbs_destroy(hgibbs_t h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
+    bw_free(h->bw);
     for (int r = 0; r < MAX_RANKS; ++r)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
@@ -1213,3 +1218,5 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
 }
 
 } // extern "C"
+
+#include "hg_bayesw.hip.h"

@@ -186,6 +186,81 @@ int hydra_chain_state(hydra_chain_t c, double* sigmaE, double* mu, double* sigma
 int hydra_chain_csv_line(hydra_chain_t c, uint32_t iteration, char* buf, size_t len);
 const int32_t* hydra_chain_order(hydra_chain_t c);
 
+/* ======================================================================== */
+/* BayesW: Weibull survival model (src/BayesW.cpp), one GPU                     */
+/* ======================================================================== */
+/* The libc rand() stream the reference's ARS draws from (src/BayesW_arms.cpp:914-919,
+ * srand at src/BayesW.cpp:1012, :877, :2029), one private copy per chain:
+ * glibc's TYPE_3 additive-feedback generator. */
+typedef struct {
+    int32_t r[31];
+    int32_t f, b;
+} hgibbs_grand_state;
+void hgibbs_grand_seed(hgibbs_grand_state* st, uint32_t seed); /* srand(seed) */
+int32_t hgibbs_grand_next(hgibbs_grand_state* st);             /* rand()      */
+
+/* arms(xinit, 4, &xl, &xr, logdens, data, &convex=1.0, 100, 0, ..., nsamp=1, ...) of
+ * src/BayesW_arms.cpp as BayesW calls it: one draw from exp(logdens) on [xl, xr].
+ * Returns 0 or the reference's error code (1003, 1004, 2000). */
+int hgibbs_ars_sample(const double* xinit4, double xl, double xr, double (*logdens)(double, void*), void* data,
+                      hgibbs_grand_state* rng, double* xsamp, int* neval);
+
+typedef struct {
+    uint64_t launches;    /* batch launches of the last sweep */
+    uint64_t nnz_updates; /* markers whose effect changed */
+    uint64_t ars_draws, ars_evals;
+    double device_ms;
+} hgibbs_w_sweep_stats;
+
+/* failure indicator (0/1) of the n_global kept individuals; allocates vi next to eps */
+int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host);
+/* mean, standard deviation (not its inverse) and sum_failure per marker, src/BayesW.cpp:1201-1232 */
+int hgibbs_w_marker_stats(hgibbs_t h, double* mave, double* sd, double* sum_failure);
+/* groups[M] (NULL = one group), mS: G x K with column 0 == 0 (src/BayesW.cpp:760-790),
+ * quad_points in {3,5,7,9,11,13,15,17,25} (:706-708) */
+int hgibbs_w_set_model(hgibbs_t h, int G, int K, const int32_t* groups_host, const double* mS, int quad_points);
+/* the N-length sums inside the scalar log densities, on the current residual:
+ *  kind 0  sum_i exp(((eps_i + p0) - p1) * p2 - EuMasc)                mu_dens,    :77-88
+ *  kind 1  sum_i exp(eps_i * p0 - EuMasc)                              alpha_dens, :132-142
+ *  kind 2  sum_i exp(((eps_i + x_ic*p0) - x_ic*p1) * p2 - EuMasc)      gamma_dens, :118-129 (c = col)
+ *  kind 3  sum_i eps_i * failure_i                                     alpha_dens */
+int hgibbs_w_reduce(hgibbs_t h, int kind, int col, double p0, double p1, double p2, double* out);
+/* vi_i = exp(alpha * eps_i - EuMasc), src/BayesW.cpp:1457-1459 */
+int hgibbs_w_refresh_vi(hgibbs_t h, double alpha);
+int hgibbs_w_get_vi(hgibbs_t h, double* vi_host /* n_local or NULL */, double* vi_sum);
+/* the per-marker streaming operator on its own (src/BayesW.cpp:1499-1523): sums of vi over all
+ * individuals / genotype 1 / genotype 2, with the marker's own effect taken out when beta_old != 0 */
+int hgibbs_w_marker_sums(hgibbs_t h, uint32_t marker, double beta_old, double alpha, double* vi_sum, double* vi_1, double* vi_2);
+/* one pass over all markers, src/BayesW.cpp:1461-1622.  rng: dist.rng (one uniform per marker);
+ * ars_rng: the rand() stream; cass: G*K counts out; beta_sqnorm: G sums of squared effects out */
+int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const double* sigmaG, const double* pi, double sumSigmaG,
+                   hgibbs_rng_state* rng, hgibbs_grand_state* ars_rng, int32_t* cass_host, double* beta_sqnorm, uint64_t* nnz_updates);
+int hgibbs_w_last_sweep_stats(hgibbs_t h, hgibbs_w_sweep_stats* out);
+int hgibbs_w_get_beta(hgibbs_t h, double* beta, int32_t* components);
+int hgibbs_w_set_beta(hgibbs_t h, const double* beta, const int32_t* components);
+
+/* ---- BayesW chain driver: the body of BayesW::runMpiGibbs_bW (src/BayesW.cpp:905-2176) ---- */
+typedef struct hydraw_chain* hydraw_chain_t;
+typedef struct {
+    uint32_t seed;         /* --seed: srand(seed) and dist.reset_rng(seed) (rank 0) */
+    int32_t shuffle;       /* --shuf-mark */
+    int32_t G, K;          /* groups; mixture components including the zero one */
+    const int32_t* groups; /* M or NULL */
+    const double* mS;      /* G*K, column 0 == 0 */
+    int32_t quad_points;   /* --quad_points */
+} hydraw_model_desc;
+int hydraw_chain_create(hgibbs_t dev, const hydraw_model_desc* model, const double* y_host, const int32_t* failure_host, hydraw_chain_t* out);
+int hydraw_chain_destroy(hydraw_chain_t c);
+int hydraw_chain_set_covariates(hydraw_chain_t c, const double* X_host, int C);
+int hydraw_chain_reseed_ars(hydraw_chain_t c, uint32_t seed);
+int hydraw_chain_iterate(hydraw_chain_t c);
+int hydraw_chain_state(hydraw_chain_t c, double* mu, double* alpha, double* sigmaG, double* pi, int32_t* m0, int32_t* cass,
+                       hgibbs_rng_state* rng, hgibbs_grand_state* ars_rng);
+int hydraw_chain_gamma(hydraw_chain_t c, double* gamma_out, int32_t* xI_out);
+const int32_t* hydraw_chain_order(hydraw_chain_t c);
+uint64_t hydraw_chain_last_nnz(hydraw_chain_t c);
+int hydraw_chain_csv_line(hydraw_chain_t c, uint32_t iteration, char* buf, size_t len);
+
 /* ---- checkpoint / restart (src/BayesRRm.cpp:842-928, :2802-2838) --------- */
 /* State a --restart run reads back from the dump files; arrays are host
  * pointers, eps has this rank's individuals.  gamma/xI may be NULL without

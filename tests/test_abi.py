@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     txt = open(os.path.join(ROOT, "include", "hgibbs.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:hgibbs|hydra)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:hgibbs|hydraw?)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_declares_what_the_binding_lists():
@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(gpu_lib):
     for name in header_symbols():
         assert hasattr(gpu_lib, name), name
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "hydra_amd", "libhgibbs.so")]).decode()
-    exported = set(re.findall(r" T ((?:hgibbs|hydra)_\w+)", out))
+    exported = set(re.findall(r" T ((?:hgibbs|hydraw?)_\w+)", out))
     assert set(header_symbols()) <= exported
 
 
