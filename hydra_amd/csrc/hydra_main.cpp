@@ -10,8 +10,10 @@
 // [--ignore-xfiles] resumes from those dumps into <name>_rs.* (:842-928,
 // :1197-1220).
 //
+// `--mpibayes bayesWMPI --failure F --quad_points Q` runs BayesW (src/BayesW.cpp:905) on one GPU.
+//
 // Not reproduced (out of scope for the hot path): sparse
-// file formats, bayesFH/bayesW, marker-sharded MPI, the .lst/tarball.
+// file formats, bayesFH, marker-sharded MPI, the .lst/tarball, --restart for bayesWMPI.
 // Multi-GPU: one process per GPU (RANK/WORLD_SIZE/LOCAL_RANK in the
 // environment, as torchrun/mpirun export them); individuals are sharded and the
 // ncclUniqueId travels through a file in --mcmc-out-dir.
@@ -48,6 +50,7 @@ struct Options { // src/options.hpp:20-138 (subset that reaches bayesMPI)
     std::vector<double> S{0.01, 0.001, 0.0001};
     bool readFromBedFile = false;
     bool restart = false, useXfilesInRestart = true; // options.hpp:33-34
+    std::string failureFile, quad_points;            // options.hpp:56-58 (bayesWMPI)
     int batch = 0, cpg = 0; // tuning knobs of this build (not hydra's)
 };
 
@@ -111,10 +114,12 @@ Options parse(int argc, const char* argv[])
         else if (a == "--covariates") {
             o.covariates = true;
             o.covariatesFile = need(i);
-        } else if (a == "--restart") o.restart = true;          // options.cpp:63-65
+        } else if (a == "--failure") o.failureFile = need(i);    // options.cpp:183-186
+        else if (a == "--quad_points") o.quad_points = need(i); // options.cpp:188-191
+        else if (a == "--restart") o.restart = true;          // options.cpp:63-65
         else if (a == "--ignore-xfiles") o.useXfilesInRestart = false; // options.cpp:67-69
         else if (a == "--sparse-dir" || a == "--sparse-basename" ||
-                 a == "--bed-to-sparse" || a == "--sparse-sync" || a == "--bed-sync" || a == "--failure" || a == "--quad_points")
+                 a == "--bed-to-sparse" || a == "--sparse-sync" || a == "--bed-sync")
             fatal("FATAL  : option " + a + " belongs to a part of hydra this build does not reproduce (SURVEY.md section 2)");
         else
             fatal("\nError: invalid option \"" + a + "\".\n"); // options.cpp:292-295
@@ -385,6 +390,231 @@ void write_rng_file(const std::string& path, const hgibbs_rng_state& st)
     for (int i = 0; i < 624; ++i) out << w[i] << (i + 1 < 624 ? " " : "");
 }
 
+// Data::readPhenFailFiles / readPhenFailCovFiles, src/data.cpp:1681-1802: .phen, .fail (and .cov)
+// are read line by line in lockstep; an individual is dropped if its phenotype is NA, its failure
+// indicator is -9, or any covariate is NA.
+void read_phen_fail(const std::string& phen, const std::string& failf, const std::string& cov, size_t numInds, std::vector<double>& y,
+                    std::vector<int32_t>& fail, std::vector<uint8_t>& keep, std::vector<double>& X, int& C)
+{
+    std::ifstream inp(phen), inf(failf), inc;
+    if (!inp) fatal("Error: can not open the phenotype file [" + phen + "] to read.");
+    if (!inf) fatal("Error: can not open the failure file [" + failf + "] to read.");
+    if (!cov.empty()) {
+        inc.open(cov);
+        if (!inc) fatal("Error: can not open the covariates file [" + cov + "] to read.");
+    }
+    keep.assign(numInds, 1);
+    y.clear();
+    fail.clear();
+    X.clear();
+    std::string lp, lf, lc;
+    size_t line = 0;
+    while (std::getline(inp, lp)) {
+        if (!std::getline(inf, lf)) fatal("FATAL  : failure file is shorter than the phenotype file");
+        if (!cov.empty() && !std::getline(inc, lc)) fatal("FATAL  : covariates file is shorter than the phenotype file");
+        if (line >= numInds) break;
+        std::vector<std::string> cp = tokens(lp, " \t"), cf = tokens(lf, " \t"), cc = tokens(lc, " \t");
+        if (cp.size() < 3 || cf.empty()) continue;
+        bool naC = false;
+        for (size_t i = 2; i < cc.size(); ++i)
+            if (cc[i] == "NA") naC = true;
+        if (cp[2] != "NA" && !naC && cf[0] != "-9") {
+            y.push_back(std::atof(cp[2].c_str()));
+            const double d = std::atof(cf[0].c_str());
+            if (d != 0.0 && d != 1.0) fatal("FATAL  : failure indicator on line " + std::to_string(line) + " is neither 0, 1 nor -9");
+            fail.push_back((int32_t)d);
+            for (size_t i = 2; i < cc.size(); ++i) X.push_back(std::stod(cc[i]));
+        } else {
+            std::cout << "NA(s) detected on line " << line << ", naP? " << cp[2] << ", naF? " << cf[0] << std::endl;
+            keep[line] = 0;
+        }
+        ++line;
+    }
+    if (line != numInds) fatal("FATAL  : phenotype/failure files cover " + std::to_string(line) + " of " + std::to_string(numInds) + " individuals");
+    C = (y.empty() || cov.empty()) ? 0 : (int)(X.size() / y.size());
+}
+
+// --mpibayes bayesWMPI: BayesW::runMpiGibbs_bW, src/BayesW.cpp:905-2176 (one GPU)
+int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
+{
+    Options opt = opt_in;
+    if (nranks > 1) fatal("FATAL  : bayesWMPI runs on one GPU in this build");
+    if (opt.failureFile.empty()) fatal("FATAL  : --failure is mandatory with --mpibayes bayesWMPI");
+    if (opt.quad_points.empty()) fatal("Possible number of quad_points = 3,5,7,9,11,13,15,17,25"); // src/BayesW.cpp:706-708
+    if (opt.restart) fatal("FATAL  : --restart is not available for bayesWMPI in this build");
+    const int quad = std::atoi(opt.quad_points.c_str());
+    std::vector<std::string> fam_ids;
+    const size_t numInds = count_fam(opt.bedFile + ".fam", &fam_ids);
+    const size_t numSnps = count_bim(opt.bedFile + ".bim");
+    std::vector<double> y, covX;
+    std::vector<int32_t> fail;
+    std::vector<uint8_t> keep;
+    int C = 0;
+    read_phen_fail(opt.phenotypeFile, opt.failureFile, opt.covariates ? opt.covariatesFile : std::string(), numInds, y, fail, keep, covX, C);
+    const unsigned numNAs = (unsigned)(numInds - y.size());
+    if (opt.numberIndividuals == 0) fatal("FATAL  : opt.numberIndividuals is zero! Set it via --number-individuals in call.");
+    if (opt.numberMarkers == 0) fatal("FATAL  : opt.numberMarkers is zero! Set it via --number-markers in call.");
+    if (opt.numberIndividuals != numInds) fatal("FATAL  : --number-individuals does not match the .fam file");
+    unsigned Mtot = opt.numberMarkers;
+    if (Mtot > numSnps) fatal("FATAL  : --number-markers exceeds the .bim file");
+    const unsigned Ntot = (unsigned)numInds - numNAs;
+    std::printf("INFO   : Full dataset includes Mtot=%d markers and Ntot=%d individuals.\n", Mtot, (int)numInds);
+
+    std::vector<int32_t> groups;
+    std::vector<std::vector<double>> mS;
+    if (!opt.groupIndexFile.empty()) { // src/BayesW.cpp:773-776
+        groups = read_groups(opt.groupIndexFile);
+        mS = read_mS(opt.groupMixtureFile);
+        if (groups.size() < Mtot) fatal("FATAL  : group file covers fewer markers than --number-markers");
+        groups.resize(Mtot);
+    } else {
+        std::vector<double> row{0.0};
+        for (double v : opt.S) row.push_back(v);
+        mS.push_back(row);
+    }
+    const int G = (int)mS.size(), K = (int)mS[0].size();
+    std::printf("numGroups = %d, data.groups.size() = %lu, Mtot = %d\n", G, (unsigned long)Mtot, Mtot); // :778
+    std::vector<double> mS_flat;
+    for (auto& r : mS) mS_flat.insert(mS_flat.end(), r.begin(), r.end());
+    if (opt.save < opt.thin) { // :981-989
+        opt.save = opt.thin;
+        std::printf("WARNING: opt.save was lower that opt.thin ; opt.save reset to opt.thin (%d)\n", opt.thin);
+    }
+    if (opt.save % opt.thin != 0) {
+        std::printf("WARNING: opt.save (= %d) was not a multiple of opt.thin (= %d)\n", opt.save, opt.thin);
+        opt.save = (opt.save / opt.thin) * opt.thin;
+        std::printf("         opt.save reset to %d, the closest multiple of opt.thin (%d)\n", opt.save, opt.thin);
+    }
+    struct stat sb;
+    if (stat(opt.mcmcOutDir.c_str(), &sb) != 0)
+        if (std::system(("mkdir -p " + opt.mcmcOutDir).c_str()) != 0) fatal("FATAL  : can not create --mcmc-out-dir");
+    const std::string base = opt.mcmcOutDir + "/" + opt.mcmcOutNam;
+
+    hgibbs_t dev = nullptr;
+    hg_check(hgibbs_create(local_rank, &dev), "hgibbs_create");
+    if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
+    const double tl0 = now_s();
+    const size_t snpLenByt = (numInds + 3) / 4;
+    {
+        std::vector<uint8_t> bed;
+        std::ifstream in(opt.bedFile + ".bed", std::ios::binary);
+        if (!in) fatal("Error: can not open the file [" + opt.bedFile + ".bed] to read.");
+        unsigned char magic[3];
+        in.read((char*)magic, 3);
+        if (!in || magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01) fatal("FATAL  : " + opt.bedFile + ".bed is not a SNP-major PLINK bed");
+        bed.resize((size_t)Mtot * snpLenByt);
+        in.read((char*)bed.data(), (std::streamsize)bed.size());
+        if ((size_t)in.gcount() != bed.size()) fatal("FATAL  : " + opt.bedFile + ".bed is shorter than M x ceil(N/4)");
+        hg_check(hgibbs_load_bed(dev, bed.data(), snpLenByt, (uint32_t)numInds, Mtot, numNAs ? keep.data() : nullptr, 0, Ntot, Ntot), "hgibbs_load_bed");
+        std::printf("INFO   : rank %3d took %.3f seconds to load  %lu bytes  =>  BW = %7.3f GB/s\n", rank, now_s() - tl0, (unsigned long)bed.size(),
+                    (double)bed.size() * 1e-9 / (now_s() - tl0));
+    }
+    if (numNAs) std::printf("INFO   : Ntot adjusted by -%d to account for NAs in phenotype file. Now Ntot=%d\n", numNAs, Ntot);
+
+    hydraw_model_desc md{};
+    md.seed = opt.seed;
+    md.shuffle = opt.shuffleMarkers;
+    md.G = G;
+    md.K = K;
+    md.groups = groups.empty() ? nullptr : groups.data();
+    md.mS = mS_flat.data();
+    md.quad_points = quad;
+    hydraw_chain_t chain = nullptr;
+    hg_check(hydraw_chain_create(dev, &md, y.data(), fail.data(), &chain), "hydraw_chain_create");
+    if (opt.covariates) hg_check(hydraw_chain_set_covariates(chain, covX.data(), C), "hydraw_chain_set_covariates");
+
+    auto open_trunc = [&](const std::string& p) {
+        FILE* f = std::fopen(p.c_str(), "wb+");
+        if (!f) fatal("FATAL  : can not create " + p);
+        return f;
+    };
+    FILE* outf = open_trunc(base + ".csv");
+    FILE* betf = open_trunc(base + ".bet");
+    FILE* cpnf = open_trunc(base + ".cpn");
+    FILE* xbetf = open_trunc(base + ".xbet");
+    FILE* xcpnf = open_trunc(base + ".xcpn");
+    FILE* gamf = open_trunc(base + ".gam"); // text, one line per thinned iteration (:1966-1977)
+    FILE* xivf = open_trunc(base + ".xiv");
+    FILE* epsf = open_trunc(base + ".eps." + std::to_string(rank));
+    FILE* mrkf = open_trunc(base + ".mrk." + std::to_string(rank));
+    for (FILE* f : {betf, xbetf, cpnf, xcpnf}) pwrite_at(f, 0, &Mtot, sizeof(unsigned)); // :1096-1101
+
+    std::vector<double> beta(Mtot), eps(Ntot), sigmaG(G), gamma(C);
+    std::vector<int32_t> comp(Mtot), m0(G), xiv(C);
+    std::vector<char> buff(50000);
+    unsigned n_thinned_saved = 0;
+    const double t_all = now_s();
+    for (unsigned iteration = 0; iteration < opt.chainLength; ++iteration) {
+        const double t0 = now_s();
+        hg_check(hydraw_chain_iterate(chain), "hydraw_chain_iterate");
+        const double t1 = now_s();
+        double mu = 0, alpha = 0;
+        hydraw_chain_state(chain, &mu, &alpha, sigmaG.data(), nullptr, m0.data(), nullptr, nullptr, nullptr);
+        double sg = 0;
+        long m0s = 0;
+        for (int g = 0; g < G; ++g) {
+            sg += sigmaG[g];
+            m0s += m0[g];
+        }
+        std::printf("%u. %ld; %.7g; %.7g; %.7g\n", iteration, m0s, mu, alpha, sg); // :1906-1908
+        std::printf("RESULT : it %4d, rank %4d: proc = %9.3f s, sync = %9.3f (%9.3f + %9.3f), n_sync = %8d (%8d + %8d) (%7.3f / %7.3f), "
+                    "betasq = %15.10f, m0 = %10d\n",
+                    iteration, rank, t1 - t0, 0.0, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, 0.0, (int)m0s);
+        std::fflush(stdout);
+
+        if (iteration % opt.thin == 0) { // :1937-2019
+            const int len = hydraw_chain_csv_line(chain, iteration, buff.data(), buff.size());
+            pwrite_at(outf, (long)n_thinned_saved * len, buff.data(), (size_t)len);
+            if (opt.covariates) {
+                hydraw_chain_gamma(chain, gamma.data(), xiv.data());
+                std::string gl(64 + 32 * (size_t)C, '\0');
+                int n = std::snprintf(&gl[0], gl.size(), "%5d", iteration);
+                for (int ii = 0; ii < C; ++ii) n += std::snprintf(&gl[n], gl.size() - n, ", %20.17f", gamma[ii]);
+                n += std::snprintf(&gl[n], gl.size() - n, "\n");
+                pwrite_at(gamf, (long)n_thinned_saved * n, gl.data(), (size_t)n);
+                if (iteration > 0 && iteration % opt.save == 0) {
+                    const unsigned nf = (unsigned)C;
+                    pwrite_at(xivf, 0, &iteration, sizeof(unsigned));
+                    pwrite_at(xivf, sizeof(unsigned), &nf, sizeof(unsigned));
+                    pwrite_at(xivf, 2 * sizeof(unsigned), xiv.data(), (size_t)C * sizeof(int));
+                }
+            }
+            hg_check(hgibbs_w_get_beta(dev, beta.data(), comp.data()), "hgibbs_w_get_beta");
+            long off = sizeof(unsigned) + (long)n_thinned_saved * (sizeof(unsigned) + (long)Mtot * sizeof(double));
+            pwrite_at(betf, off, &iteration, sizeof(unsigned));
+            pwrite_at(betf, off + sizeof(unsigned), beta.data(), (size_t)Mtot * sizeof(double));
+            off = sizeof(unsigned) + (long)n_thinned_saved * (sizeof(unsigned) + (long)Mtot * sizeof(int));
+            pwrite_at(cpnf, off, &iteration, sizeof(unsigned));
+            pwrite_at(cpnf, off + sizeof(unsigned), comp.data(), (size_t)Mtot * sizeof(int));
+            n_thinned_saved += 1;
+        }
+        if (iteration > 0 && iteration % opt.save == 0) { // :2028-2052
+            hg_check(hydraw_chain_reseed_ars(chain, opt.seed + iteration), "hydraw_chain_reseed_ars"); // srand(opt.seed + iteration)
+            hgibbs_rng_state rst;
+            hydraw_chain_state(chain, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &rst, nullptr);
+            write_rng_file(base + ".rng." + std::to_string(rank), rst);
+            hg_check(hgibbs_get_residual(dev, eps.data()), "hgibbs_get_residual");
+            hg_check(hgibbs_w_get_beta(dev, beta.data(), comp.data()), "hgibbs_w_get_beta");
+            pwrite_at(epsf, 0, &iteration, sizeof(unsigned));
+            pwrite_at(epsf, sizeof(unsigned), &Ntot, sizeof(unsigned));
+            pwrite_at(epsf, 2 * sizeof(unsigned), eps.data(), (size_t)Ntot * sizeof(double));
+            pwrite_at(mrkf, 0, &iteration, sizeof(unsigned));
+            pwrite_at(mrkf, sizeof(unsigned), &Mtot, sizeof(unsigned));
+            pwrite_at(mrkf, 2 * sizeof(unsigned), hydraw_chain_order(chain), (size_t)Mtot * sizeof(int));
+            pwrite_at(xbetf, sizeof(unsigned), &iteration, sizeof(unsigned));
+            pwrite_at(xcpnf, sizeof(unsigned), &iteration, sizeof(unsigned));
+            pwrite_at(xbetf, 2 * sizeof(unsigned), beta.data(), (size_t)Mtot * sizeof(double));
+            pwrite_at(xcpnf, 2 * sizeof(unsigned), comp.data(), (size_t)Mtot * sizeof(int));
+        }
+    }
+    std::printf("INFO   : rank %4d, time to process the data: %.3f sec\n", rank, now_s() - t_all);
+    for (FILE* f : {outf, betf, cpnf, xbetf, xcpnf, gamf, xivf, epsf, mrkf})
+        if (f) std::fclose(f);
+    hydraw_chain_destroy(chain);
+    hgibbs_destroy(dev);
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, const char* argv[])
@@ -394,9 +624,9 @@ int main(int argc, const char* argv[])
         return 1;
     }
     Options opt = parse(argc, argv);
-    if (!(opt.bayesType == "bayesMPI" && opt.analysisType == "RAM")) {
+    if (!((opt.bayesType == "bayesMPI" || opt.bayesType == "bayesWMPI") && opt.analysisType == "RAM")) {
         std::cerr << "\n Error: Wrong analysis requested: " << opt.analysisType << " + " << opt.bayesType
-                  << " (this build reproduces --mpibayes bayesMPI)" << std::endl;
+                  << " (this build reproduces --mpibayes bayesMPI and bayesWMPI)" << std::endl;
         return 0; // the reference catches the throw and still returns 0 (main.cpp:179-189)
     }
     if (!opt.readFromBedFile) fatal("FATAL: either go for BED, SPARSE or BOTH (this build reads --bfile)");
@@ -409,6 +639,7 @@ int main(int argc, const char* argv[])
     const int rank = (e = std::getenv("RANK")) ? std::atoi(e) : 0;
     const int nranks = (e = std::getenv("WORLD_SIZE")) ? std::atoi(e) : 1;
     const int local_rank = (e = std::getenv("LOCAL_RANK")) ? std::atoi(e) : rank;
+    if (opt.bayesType == "bayesWMPI") return run_bayesw(opt, rank, nranks, local_rank); // main.cpp:164-167
 
     // ---- inputs (main.cpp:69-70,88; BayesRRm.cpp:969-997) -------------------
     std::vector<std::string> fam_ids;

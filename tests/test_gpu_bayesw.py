@@ -170,3 +170,91 @@ def test_argument_errors():
         ops.set_model(np.array([[0.0] + [0.01 * k for k in range(1, 10)]]), quad=5)
     with pytest.raises(capi.HgError, match="already initialised"):
         capi.BwOps(dev, fail)
+
+
+# ---- command line: --mpibayes bayesWMPI (src/main.cpp:164-167, src/BayesW.cpp:905-2176) ----------
+import os
+import struct
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "hydra_amd", "bin", "hydra_mi355x")
+
+
+def _read_hist(path, M, dtype):
+    raw = open(path, "rb").read()
+    assert struct.unpack("<I", raw[:4])[0] == M
+    rec = 4 + M * np.dtype(dtype).itemsize
+    assert (len(raw) - 4) % rec == 0
+    its = [struct.unpack("<I", raw[4 + k * rec:8 + k * rec])[0] for k in range((len(raw) - 4) // rec)]
+    vals = [np.frombuffer(raw[8 + k * rec:4 + (k + 1) * rec], dtype=dtype) for k in range(len(its))]
+    return its, np.array(vals)
+
+
+@pytest.mark.parametrize("with_cov", [False, True])
+def test_cli_bayesw_files_match_oracle(oracle, tmp_path, with_cov):
+    M, N, iters, seed, save = 90, 700, 7, 31, 3
+    geno, bed, y, fail = make_case(M, N, seed=41, missing_rate=0.02)
+    X = np.random.default_rng(3).normal(size=(N, 2)) * 0.2
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    na_rows, minus9 = [5, 300], [17]
+    synth.write_plink(prefix, bed, N, y=y, na_rows=na_rows)
+    with open(prefix + ".fail", "w") as f:
+        for i in range(N):
+            f.write("%d\n" % (-9 if i in minus9 else fail[i]))
+    cmd = [EXE, "--mpibayes", "bayesWMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--failure", prefix + ".fail", "--quad_points", "7",
+           "--mcmc-out-dir", out, "--mcmc-out-name", "w", "--number-individuals", str(N), "--number-markers", str(M), "--chain-length", str(iters),
+           "--thin", "1", "--save", str(save), "--seed", str(seed), "--S", "0.001,0.01"]
+    drop = set(na_rows + minus9)
+    if with_cov:
+        with open(prefix + ".cov", "w") as f:
+            for i in range(N):
+                f.write("fam%d ind%d %s %r\n" % (i, i, "NA" if i == 44 else repr(float(X[i, 0])), float(X[i, 1])))
+        cmd += ["--covariates", prefix + ".cov"]
+        drop.add(44)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RESULT : it    0, rank    0: proc =" in r.stdout
+    keep = np.array([i not in drop for i in range(N)])
+    ref = orc.BwChain(oracle, synth.pack_bed_columns(geno[:, keep]), int(keep.sum()), y[keep], fail[keep], mS=np.array([[0.0, 0.001, 0.01]]),
+                      seed=seed, quad=7)
+    if with_cov:
+        ref.set_covariates(X[keep])
+    its, betas = _read_hist(out + "/w.bet", M, np.float64)
+    _, comps = _read_hist(out + "/w.cpn", M, np.int32)
+    csv = open(out + "/w.csv").read().splitlines()
+    gam = open(out + "/w.gam").read().splitlines()
+    assert its == list(range(iters)) and len(csv) == iters and len(gam) == (iters if with_cov else 0)
+    for it in range(iters):
+        ref.iterate()
+        assert np.array_equal(comps[it], ref.arr("components")) and close(betas[it], ref.arr("beta"))
+        got, want = [float(x) for x in csv[it].split(",")], [float(x) for x in ref.csv_line(it).split(",")]
+        assert len(csv[it]) + 1 == len(ref.csv_line(it)) and close(got, want)
+        if with_cov:
+            g = [float(x) for x in gam[it].split(",")]
+            assert g[0] == it and close(g[1:], ref.arr("gamma"))
+        if it > 0 and it % save == 0:
+            ref.reseed_ars(seed + it)  # srand(opt.seed + iteration) at every checkpoint, src/BayesW.cpp:2029
+            if it == 6:
+                it_e, n_e = struct.unpack("<II", open(out + "/w.eps.0", "rb").read()[:8])
+                assert (it_e, n_e) == (6, int(keep.sum()))
+                eps = np.frombuffer(open(out + "/w.eps.0", "rb").read()[8:], dtype=np.float64)
+                assert close(eps, ref.arr("eps"))
+    assert len(open(out + "/w.rng.0").read().split()) == 624
+    xb = open(out + "/w.xbet", "rb").read()
+    assert struct.unpack("<II", xb[:8]) == (M, 6) and np.array_equal(np.frombuffer(xb[8:], dtype=np.float64), betas[6])
+
+
+def test_cli_bayesw_refuses_bad_options(tmp_path):
+    _, bed, y, fail = make_case(10, 40)
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, bed, 40, y=y)
+    np.savetxt(prefix + ".fail", fail, fmt="%d")
+    base = [EXE, "--mpibayes", "bayesWMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--mcmc-out-dir", out, "--mcmc-out-name", "w",
+            "--number-individuals", "40", "--number-markers", "10", "--chain-length", "2", "--seed", "1"]
+    r = subprocess.run(base + ["--quad_points", "9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--failure is mandatory" in r.stderr
+    r = subprocess.run(base + ["--failure", prefix + ".fail", "--quad_points", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Possible number of quad_points = 3,5,7,9,11,13,15,17,25" in r.stderr
+    r = subprocess.run(base + ["--failure", prefix + ".fail"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Possible number of quad_points" in r.stderr
