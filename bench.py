@@ -32,6 +32,11 @@ CONFIGS = {
     "c3": (200000, 500000, 2, [[0.0, 0.001, 0.01, 0.1], [0.0, 0.001, 0.01, 0.1]]),
     "c4": (500000, 1000000, 1, [[0.0, 0.0001, 0.001, 0.01]]),
 }
+# BayesW (Weibull survival, SURVEY.md 8f-1 / BASELINE config 5): name: (N, M, mS, quad_points)
+BW_CONFIGS = {
+    "c5": (5000, 10000, [[0.0, 0.001, 0.01]], 25),       # the shape of example/t_M10K_N_5K + Weibull.phen/.fail
+    "w100k": (100000, 100000, [[0.0, 0.0001, 0.001, 0.01]], 9),
+}
 HBM_PEAK_GBPS = 8000.0  # MI355X nominal (MI355X_MICROARCH.md); ~6300 measured copy ceiling
 
 
@@ -40,6 +45,14 @@ def algorithmic_bytes(n_local, M, nnz):
     plus 16 N_g for every marker whose effect changed; per iteration 16 N_g + 20 M."""
     col = (n_local + 3) // 4
     return M * (col + 8 * n_local) + nnz * 16 * n_local + 16 * n_local + 20 * M
+
+
+def algorithmic_bytes_bw(n, M, nnz, nshift):
+    """BayesW, per marker: the packed column + vi (ceil(N/4) + 8N); a marker whose effect was not
+    zero reads eps instead of vi (same count); every changed effect rewrites eps and vi
+    (8N read + 16N write)."""
+    col = (n + 3) // 4
+    return M * (col + 8 * n) + nnz * 24 * n
 
 
 def measured_traffic(N, batch, world):
@@ -187,12 +200,105 @@ def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
     return None
 
 
+def make_survival_on_device(dev, N, M, seed=44, h2=0.5, causal_frac=0.01, mu=4.1, alpha=10.0, censor_rate=0.1):
+    """Weibull log-times shaped like example/Weibull.phen + .fail (mu 4.1, alpha 10, h2 0.5, 10% censored):
+    genetic values from the product's own residual-update operator on the resident genotypes."""
+    rng = np.random.default_rng(seed)
+    m_causal = max(1, int(round(M * causal_frac)))
+    causal = rng.choice(M, size=m_causal, replace=False)
+    var_e = np.pi ** 2 / (6.0 * alpha ** 2)
+    beta = rng.normal(0.0, np.sqrt(var_e * h2 / (1.0 - h2) / m_causal), size=m_causal)
+    dev.set_residual(np.zeros(N))
+    for j, b in zip(causal, beta):
+        dev.update_marker(int(j), -float(b))
+    gval = dev.get_residual()
+    y = mu + gval + (np.log(rng.exponential(1.0, size=N)) + 0.577215664901532) / alpha
+    fail = (rng.random(N) >= censor_rate).astype(np.int32)
+    return np.where(fail == 1, y, y - rng.exponential(0.05, size=N)), fail
+
+
+def cpu_baseline_bw(dev, y, fail, N, M, mS, quad, sample_markers):
+    """BayesW: the oracle's restatement of hydra's sampler (single thread, -O2) on the first
+    `sample_markers` columns, one iteration after a warm-up one, in a child process."""
+    import subprocess
+    import tempfile
+    ms = min(sample_markers, M)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sample.npz")
+        np.savez(path, bed=dev.get_bed(0, ms), y=y, fail=fail, N=np.array(N), mS=np.array(mS), quad=np.array(quad))
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), path, "liboracle.so", "1", "bayesw"],
+                                 capture_output=True, text=True, timeout=900)
+            if out.returncode == 0:
+                r = json.loads(out.stdout.strip().splitlines()[-1])
+                return {"value": r["markers_per_s"], "unit": "markers/s", "cores": 1, "kind": "port",
+                        "sample": "restated hydra BayesW sampler (sequential sums, libm exp, ARS), first %d of %d markers, N=%d, "
+                                  "1 Gibbs iteration after 1 warm-up, liboracle.so, -O2" % (ms, M, N)}
+            print("cpu_baseline (bayesw) failed (rc %d): %s" % (out.returncode, out.stderr[-400:]), file=sys.stderr)
+        except Exception as e:
+            print("cpu_baseline (bayesw) failed: %r" % (e,), file=sys.stderr)
+    return None
+
+
+def main_bayesw(args):
+    """One GPU; a step = one full BayesW iteration (mu, alpha by ARS, vi, shuffle, sweep, sigmaG, pi)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("the BayesW workloads run on one GPU (SURVEY.md 8f-1)")
+    from hydra_amd import capi
+    N, M, mS, quad = BW_CONFIGS[args.config]
+    N, M = args.N or N, args.M or M
+    dev = capi.Device(int(os.environ.get("HGIBBS_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    t_setup = time.perf_counter()
+    dev.synth_bed(N, M, seed=42, missing_rate=args.missing)
+    y, fail = make_survival_on_device(dev, N, M)
+    if args.batch:
+        dev.set_option("batch", args.batch)
+    dev.set_option("w_kernel_timing", 1)
+    chain = capi.BwChain(dev, y, fail, mS=np.array(mS), seed=1222, shuffle=1, quad=quad)
+    t_setup = time.perf_counter() - t_setup
+    for _ in range(args.warmup):
+        chain.iterate()
+    stats = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.iterate()
+        stats.append(chain.sweep_stats())
+    dt = time.perf_counter() - t0
+    K = args.steps
+    launches = sum(s["launches"] for s in stats)
+    nnz = sum(s["nnz_updates"] for s in stats)
+    kernel_ms_avg = sum(s["sums_kernel_ms"] for s in stats) / max(1, launches)
+    bytes_alg = sum(algorithmic_bytes_bw(N, M, s["nnz_updates"], 0) for s in stats)
+    # the dominant kernel's share: the per-marker streaming reads (updates run in k_bw_refresh)
+    bytes_sums = K * M * ((N + 3) // 4 + 8 * N)
+    achieved = (bytes_sums / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9 if kernel_ms_avg > 0 else 0.0
+    out = {
+        "metric": "Gibbs markers/sec/iter", "value": M * K / dt, "unit": "markers/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BayesW %s: N=%d individuals x M=%d markers, K=%d mixture, %d quadrature points, .bed resident in HBM, 1 GPU"
+                               % (args.config, N, M, len(mS[0]), quad),
+                   "N": N, "M": M, "batch": args.batch or "auto", "nnz_updates_per_iter": nnz / K, "launches_per_iter": launches / K,
+                   "ars_draws_per_iter": sum(s["ars_draws"] for s in stats) / K, "setup_s": t_setup},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "k_bw_sums", "kernel_ms_avg": kernel_ms_avg,
+                     "algorithmic_bytes_per_launch": bytes_sums / max(1, launches),
+                     "algorithmic_bytes_per_iter_all_kernels": bytes_alg / K,
+                     "sweep_ms_per_iter": sum(s["device_ms"] for s in stats) / K},
+    }
+    if not args.no_cpu_baseline:
+        sample = args.cpu_sample or max(64, min(M, int(1.0e9 / max(1, N))))
+        out["cpu_baseline"] = cpu_baseline_bw(dev, y, fail, N, M, mS, quad, sample)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS) + sorted(BW_CONFIGS))
     ap.add_argument("--N", type=int, default=0, help="override individuals")
     ap.add_argument("--M", type=int, default=0, help="override markers")
     ap.add_argument("--batch", type=int, default=0, help="speculative batch width (0 = library default)")
@@ -203,6 +309,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="markers in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
+    if args.config in BW_CONFIGS:
+        return main_bayesw(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

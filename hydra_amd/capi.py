@@ -53,7 +53,7 @@ class GrandState(C.Structure):
 
 class WSweepStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("ars_draws", C.c_uint64), ("ars_evals", C.c_uint64),
-                ("device_ms", C.c_double)]
+                ("device_ms", C.c_double), ("sums_kernel_ms", C.c_double)]
 
 
 class WModelDesc(C.Structure):

@@ -8,12 +8,14 @@
 // chosen -- one adaptive-rejection draw of the effect on scalars only; a non-zero change of the
 // effect updates eps and refreshes vi.  Here:
 //   k_bw_sums     one launch = the masked sums of up to 256 markers against the SAME vi (valid
-//                 until the first effect changes), 8 columns per workgroup per pass over vi;
-//                 the last-arriving workgroup reduces in fixed order, evaluates the quadrature
-//                 for every column in parallel, walks the components with the column's uniform
-//                 and reports the first column that is an event (slab chosen, or an effect that
-//                 was non-zero).  A marker whose effect was non-zero rides along as one extra
-//                 column group computing exp(alpha*(eps + effect*x) - EuMasc) on the fly.
+//                 until the first effect changes), 8 columns per workgroup per pass over vi.
+//                 A marker whose effect was non-zero rides along as one extra column group
+//                 computing exp(alpha*(eps + effect*x) - EuMasc) on the fly.
+//   k_bw_tail     one wavefront per column: fixed-order reduction of the slice partials, every
+//                 (component, node) term of the quadrature on its own lane, the walk over the
+//                 components with the column's uniform; the last wavefront reports the first
+//                 column that is an event (slab chosen, or an effect that was non-zero) straight
+//                 into pinned host memory.
 //   k_bw_refresh  eps += delta(genotype) for the event's marker fused with vi = exp(alpha*eps - EuMasc)
 //                 and the block partials of sum(vi).
 //   k_bw_reduce   the N-length sums inside the log densities of mu, alpha and the covariates.
@@ -33,6 +35,7 @@ struct BwResult {
     uint32_t event; // index in the batch of the first event, == columns in the batch if none
     int32_t k;      // component picked for the event column
     double vi_sum, vi_1, vi_2; // its masked sums
+    unsigned long long seq;    // written last: the batch this result belongs to
 };
 
 struct BwBatchParams {
@@ -57,10 +60,14 @@ struct BwBatchParams {
     int K;
     const double *ghx, *ghw;
     int quad;
-    const double* vi_sum;
-    BwResult* result;
-    int32_t* picks;   // MAX_BATCH + 1
-    double* col_sums; // (MAX_BATCH + 1) x 3, for the single-marker operator and tests
+    const double* vipart; // block partials of sum(vi) from the last refresh
+    uint32_t n_vipart;
+    BwResult* result;     // pinned host memory
+    unsigned long long seq;
+    int32_t* picks;       // MAX_BATCH + 1
+    int32_t* col_k;       // MAX_BATCH + 1
+    double* col_sums;     // (MAX_BATCH + 1) x 3
+    uint32_t* first_event;
 };
 
 // eps (+ delta of one marker) -> eps, vi; per-block partial of sum(vi).  marker < 0: refresh only.
@@ -226,13 +233,11 @@ template <int CPG>
 __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
 {
     __shared__ double wpart[BLOCK_WAVES][2 * CPG + 4];
-    __shared__ uint32_t s_flag[2]; // [0] last arriver, [1] first event
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ngn = (p.ncols + CPG - 1) / CPG;
     const uint32_t S = p.slices;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
     const uint32_t ntg = p.n_pad / BLOCK_IND;
-    const uint32_t nb = p.ncols + (p.shifted_marker >= 0 ? 1u : 0u);
 
     if (group < ngn) {
         const uint32_t c0 = group * CPG;
@@ -315,54 +320,96 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
             __hip_atomic_store(p.partials + (size_t)slice * BW_ROWS + 2 * MAX_BATCH + tid, v, HG_RLX_AGENT);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        s_flag[0] = (t == gridDim.x - 1u) ? 1u : 0u;
-        s_flag[1] = nb;
-    }
-    __syncthreads();
-    if (!s_flag[0]) return;
+}
 
-    // ---- last-arriving workgroup: fixed-order reduction, quadrature, walk ------------------------
-    if (tid == 0) __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
-    bool is_event = false;
-    int k = 0;
-    bw::MarkerSums sums{0.0, 0.0, 0.0};
-    if (tid < (int)nb) {
-        const bool shifted = (uint32_t)tid >= p.ncols;
-        const uint32_t r0 = shifted ? 2 * MAX_BATCH : 2 * (uint32_t)tid;
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-        for (uint32_t s = 0; s < S; ++s) {
-            const double* row = p.partials + (size_t)s * BW_ROWS + r0;
-            t0 += __hip_atomic_load(row, HG_RLX_AGENT);
-            t1 += __hip_atomic_load(row + 1, HG_RLX_AGENT);
-            if (shifted) t2 += __hip_atomic_load(row + 2, HG_RLX_AGENT);
-        }
-        if (shifted) sums = bw::MarkerSums{t0, t1, t2};
-        else sums = bw::MarkerSums{*p.vi_sum, t0, t1};
-        const int marker = shifted ? p.shifted_marker : p.markers[tid];
-        const int grp = p.groups[marker];
-        double ml[bw::MAX_K];
-        bw::marginals(p.quad, p.ghx, p.ghw, p.K, p.pi + (size_t)grp * p.K, p.cva + (size_t)grp * (p.K - 1), p.alpha, p.sigmaG[grp],
-                      p.sumfail[marker], sums, p.mave[marker], p.sd[marker], ml);
-        k = bw::pick_component(p.K, ml, p.p_unif[tid]);
-        is_event = shifted || k != 0;
-        p.picks[tid] = k;
-        if (p.col_sums) {
-            p.col_sums[3 * tid] = sums.vi_sum;
-            p.col_sums[3 * tid + 1] = sums.vi_1;
-            p.col_sums[3 * tid + 2] = sums.vi_2;
-        }
-        if (is_event) atomicMin(&s_flag[1], (uint32_t)tid);
+// One wavefront per column: reduce the column's slice partials, evaluate every (component, node)
+// term of the quadrature on its own lane, sum them in the reference's order, walk the components
+// with the column's uniform.  The last wavefront to finish reports the first event of the batch
+// straight into pinned host memory (data, fence, then the sequence number the host is polling).
+__global__ __launch_bounds__(WAVE) void k_bw_tail(BwBatchParams p)
+{
+    __shared__ double terms[(bw::MAX_K - 1) * 24];
+    __shared__ double s_ml[bw::MAX_K];
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x;
+    const uint32_t col = blockIdx.x;
+    const uint32_t nb = p.ncols + (p.shifted_marker >= 0 ? 1u : 0u);
+    const bool shifted = col >= p.ncols;
+    const uint32_t S = p.slices;
+
+    // fixed-order (wave tree) sums over the S <= 64 slices; sum(vi) from the refresh kernel's block partials
+    const uint32_t r0 = shifted ? 2 * MAX_BATCH : 2 * col;
+    const double* row = p.partials + (size_t)lane * BW_ROWS + r0;
+    const bool live = (uint32_t)lane < S;
+    double t0 = live ? __hip_atomic_load(row, HG_RLX_AGENT) : 0.0;
+    double t1 = live ? __hip_atomic_load(row + 1, HG_RLX_AGENT) : 0.0;
+    double t2 = (live && shifted) ? __hip_atomic_load(row + 2, HG_RLX_AGENT) : 0.0;
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    bw::MarkerSums sums;
+    if (shifted) {
+        t2 = wave_sum(t2);
+        sums = bw::MarkerSums{t0, t1, t2};
+    } else {
+        double v = 0.0;
+        for (uint32_t b = lane; b < p.n_vipart; b += WAVE) v += p.vipart[b];
+        sums = bw::MarkerSums{wave_sum(v), t0, t1};
+    }
+    const int marker = shifted ? p.shifted_marker : p.markers[col];
+    const int grp = p.groups[marker];
+    const int K = p.K, Q = p.quad, km1 = K - 1;
+    const double mean = p.mave[marker], sd = p.sd[marker], alpha = p.alpha, sigmaG = p.sigmaG[grp], dj = p.sumfail[marker];
+    const double vi_0 = sums.vi_sum - sums.vi_1 - sums.vi_2;
+    const double exp_sum = (sums.vi_1 * (1 - 2 * mean) + 4 * (1 - mean) * sums.vi_2 + sums.vi_sum * mean * mean) / (sd * sd);
+    const double* cva = p.cva + (size_t)grp * km1;
+    for (int idx = lane; idx < km1 * (Q - 1); idx += WAVE) { // src/BayesW.cpp:161-169, :713-726
+        const int i = idx / (Q - 1), q = idx % (Q - 1);
+        const double sigma = 1.0 / sqrt(1 + alpha * alpha * sigmaG * cva[i] * exp_sum);
+        terms[idx] = p.ghw[q] * bw::gh_integrand(sigma * p.ghx[q], alpha, dj, sqrt(2 * cva[i] * sigmaG), sums.vi_sum, sums.vi_2, sums.vi_1, vi_0, sd, mean / sd);
     }
     __syncthreads();
-    const uint32_t ev = s_flag[1];
-    if (ev == nb) {
-        if (tid == 0) *p.result = BwResult{nb, 0, 0.0, 0.0, 0.0};
-    } else if ((uint32_t)tid == ev) {
-        *p.result = BwResult{ev, k, sums.vi_sum, sums.vi_1, sums.vi_2};
+    if (lane < km1) { // the reference's order: w1 f1 + w2 f2 + ... + w_{n-1} f_{n-1} + w_n, times sigma, times pi
+        const double sigma = 1.0 / sqrt(1 + alpha * alpha * sigmaG * cva[lane] * exp_sum);
+        double temp = terms[lane * (Q - 1)];
+        for (int q = 1; q < Q - 1; ++q) temp = temp + terms[lane * (Q - 1) + q];
+        temp = temp + p.ghw[Q - 1];
+        s_ml[lane + 1] = p.pi[(size_t)grp * K + lane + 1] * (sigma * temp);
+    }
+    if (lane == 0) s_ml[0] = p.pi[(size_t)grp * K] * bw::SQRT_PI;
+    __syncthreads();
+    if (lane == 0) {
+        double ml[bw::MAX_K];
+        for (int k = 0; k < K; ++k) ml[k] = s_ml[k];
+        const int k = bw::pick_component(K, ml, p.p_unif[col]);
+        p.picks[col] = k;
+        __hip_atomic_store(p.col_sums + 3 * col, sums.vi_sum, HG_RLX_AGENT);
+        __hip_atomic_store(p.col_sums + 3 * col + 1, sums.vi_1, HG_RLX_AGENT);
+        __hip_atomic_store(p.col_sums + 3 * col + 2, sums.vi_2, HG_RLX_AGENT);
+        __hip_atomic_store(p.col_k + col, k, HG_RLX_AGENT);
+        if (shifted || k != 0) __hip_atomic_fetch_min(p.first_event, col, HG_RLX_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+        if (s_last) {
+            const uint32_t ev = __hip_atomic_load(p.first_event, HG_RLX_AGENT);
+            BwResult r{nb, 0, 0.0, 0.0, 0.0, 0ull};
+            if (ev < nb) {
+                r.event = ev;
+                r.k = __hip_atomic_load(p.col_k + ev, HG_RLX_AGENT);
+                r.vi_sum = __hip_atomic_load(p.col_sums + 3 * ev, HG_RLX_AGENT);
+                r.vi_1 = __hip_atomic_load(p.col_sums + 3 * ev + 1, HG_RLX_AGENT);
+                r.vi_2 = __hip_atomic_load(p.col_sums + 3 * ev + 2, HG_RLX_AGENT);
+            }
+            __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
+            __hip_atomic_store(p.first_event, 0xffffffffu, HG_RLX_AGENT);
+            __hip_atomic_store(&p.result->event, r.event, HG_RLX_SYSTEM);
+            __hip_atomic_store(&p.result->k, r.k, HG_RLX_SYSTEM);
+            __hip_atomic_store(&p.result->vi_sum, r.vi_sum, HG_RLX_SYSTEM);
+            __hip_atomic_store(&p.result->vi_1, r.vi_1, HG_RLX_SYSTEM);
+            __hip_atomic_store(&p.result->vi_2, r.vi_2, HG_RLX_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(&p.result->seq, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -380,8 +427,12 @@ struct BwState {
     double *d_ghx = nullptr, *d_ghw = nullptr;
     double* d_unif = nullptr;
     double* partials = nullptr;
-    BwResult* d_result = nullptr;
-    BwResult* h_result = nullptr; // pinned
+    BwResult* h_result = nullptr; // pinned, written by the device
+    unsigned long long seq = 0;
+    double* vipart = nullptr; // block partials of sum(vi) from the last refresh
+    int32_t* d_colk = nullptr;
+    uint32_t* d_first_event = nullptr;
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;
     int32_t* d_picks = nullptr;
     double* d_colsums = nullptr;
     std::vector<double> mave, sd, sumfail, cva, beta;
@@ -397,10 +448,12 @@ static void bw_free(BwState* b)
 {
     if (!b) return;
     void* ptrs[] = {b->vi, b->failspread, b->vi_sum, b->d_mave, b->d_sd, b->d_sumfail, b->d_cva, b->d_pi, b->d_sigmaG, b->d_ghx, b->d_ghw,
-                    b->d_unif, b->partials, b->d_result, b->d_picks, b->d_colsums};
+                    b->d_unif, b->partials, b->d_picks, b->d_colsums, b->vipart, b->d_colk, b->d_first_event};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_result) (void)hipHostFree(b->h_result);
+    if (b->evk0) (void)hipEventDestroy(b->evk0);
+    if (b->evk1) (void)hipEventDestroy(b->evk1);
     delete b;
 }
 
@@ -447,8 +500,14 @@ int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host)
     HIP_TRY(hipMalloc(&b->d_sumfail, (size_t)h->M * sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_unif, (size_t)h->M * sizeof(double)));
     HIP_TRY(hipMalloc(&b->partials, (size_t)S_CAP * BW_ROWS * sizeof(double)));
-    HIP_TRY(hipMalloc(&b->d_result, sizeof(BwResult)));
     HIP_TRY(hipHostMalloc(&b->h_result, sizeof(BwResult)));
+    std::memset(b->h_result, 0, sizeof(BwResult));
+    HIP_TRY(hipMalloc(&b->vipart, (size_t)(h->n_pad / BLOCK_IND) * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_colk, (MAX_BATCH + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&b->d_first_event, sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(b->d_first_event, 0xff, sizeof(uint32_t), h->stream));
+    HIP_TRY(hipEventCreate(&b->evk0));
+    HIP_TRY(hipEventCreate(&b->evk1));
     HIP_TRY(hipMalloc(&b->d_picks, (MAX_BATCH + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&b->d_colsums, (size_t)(MAX_BATCH + 1) * 3 * sizeof(double)));
     int32_t* d_fail = nullptr;
@@ -574,8 +633,9 @@ int hgibbs_w_refresh_vi(hgibbs_t h, double alpha)
     if (bw_need(h, "hgibbs_w_refresh_vi")) return 1;
     HIP_TRY(hipSetDevice(h->device));
     const uint32_t nblk = h->n_pad / BLOCK_IND;
-    k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, -1, 0.0, 0.0, 0.0, h->eps[h->eps_cur], h->bw->vi, alpha, h->n_local, h->scratch);
-    return bw_final(h, nblk, h->bw->vi_sum);
+    k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, -1, 0.0, 0.0, 0.0, h->eps[h->eps_cur], h->bw->vi, alpha, h->n_local, h->bw->vipart);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int hgibbs_w_get_vi(hgibbs_t h, double* vi_host, double* vi_sum)
@@ -591,7 +651,12 @@ int hgibbs_w_get_vi(hgibbs_t h, double* vi_host, double* vi_sum)
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipFree(tmp));
     }
-    if (vi_sum) HIP_TRY(hipMemcpy(vi_sum, h->bw->vi_sum, sizeof(double), hipMemcpyDeviceToHost));
+    if (vi_sum) {
+        k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->bw->vipart, h->n_pad / BLOCK_IND, 1, h->bw->vi_sum);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(vi_sum, h->bw->vi_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 
@@ -674,6 +739,7 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
     const uint32_t batch_cap = std::min<uint32_t>(h->batch ? h->batch : MAX_BATCH, MAX_BATCH);
     constexpr int CPG = 8;
     uint64_t nnz = 0, launches = 0, ars_draws = 0, ars_evals = 0;
+    double sums_ms = 0.0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     uint32_t cursor = 0;
     hg::GlibcRand* gr = reinterpret_cast<hg::GlibcRand*>(ars_rng);
@@ -727,15 +793,44 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         p.ghx = b->d_ghx;
         p.ghw = b->d_ghw;
         p.quad = b->quad;
-        p.vi_sum = b->vi_sum;
-        p.result = b->d_result;
+        p.vipart = b->vipart;
+        p.n_vipart = nblk;
+        p.result = b->h_result;
+        p.seq = ++b->seq;
         p.picks = b->d_picks;
-        p.col_sums = h->debug_timing ? b->d_colsums : nullptr;
+        p.col_k = b->d_colk;
+        p.col_sums = b->d_colsums;
+        p.first_event = b->d_first_event;
+        if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk0, h->stream));
         k_bw_sums<CPG><<<S * ngroups, BLOCK, 0, h->stream>>>(p);
+        if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk1, h->stream));
+        k_bw_tail<<<nb, WAVE, 0, h->stream>>>(p);
         HIP_TRY(hipGetLastError());
         ++launches;
-        HIP_TRY(hipMemcpyAsync(b->h_result, b->d_result, sizeof(BwResult), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // the tail writes the result into pinned memory, the sequence number last: poll it, and fall
+        // back to the stream's completion so that a failed launch cannot hang the host
+        {
+            volatile unsigned long long* seqp = &b->h_result->seq;
+            uint32_t spins = 0;
+            while (*seqp != p.seq) {
+                if ((++spins & 0x3ffu) == 0) {
+                    const hipError_t q = hipStreamQuery(h->stream);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail("hgibbs_w_sweep: %s", hipGetErrorString(q));
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (*seqp != p.seq) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (*seqp != p.seq) return fail("hgibbs_w_sweep: the batch result never arrived (seq %llu, expected %llu)", *seqp, p.seq);
+            }
+        }
+        if (h->w_kernel_timing) {
+            HIP_TRY(hipEventSynchronize(b->evk1));
+            float kms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&kms, b->evk0, b->evk1));
+            sums_ms += kms;
+        }
         const BwResult r = *b->h_result;
         if (r.event > nb) return fail("hgibbs_w_sweep: device reported event %u in a batch of %u", r.event, nb);
         // markers before the event keep a zero effect (src/BayesW.cpp:1541-1546)
@@ -778,8 +873,7 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
             double dv[3];
             bw::delta_values(deltaBeta, b->mave[mk], b->sd[mk], dv);
             k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, mk, dv[0], dv[1], dv[2], h->eps[h->eps_cur], b->vi, alpha, h->n_local,
-                                                        h->scratch);
-            if (bw_final(h, nblk, b->vi_sum)) return 1;
+                                                        b->vipart);
             ++nnz;
         }
         cursor += r.event + 1;
@@ -794,6 +888,7 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
     b->stats.ars_draws = ars_draws;
     b->stats.ars_evals = ars_evals;
     b->stats.device_ms = ms;
+    b->stats.sums_kernel_ms = sums_ms;
     return 0;
 }
 

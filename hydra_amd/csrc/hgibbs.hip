@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -101,6 +102,7 @@ struct hgibbs_ctx {
     int32_t* s_ga = nullptr;
     unsigned long long* dbg = nullptr; // 8 words, device
     bool debug_timing = false;
+    bool w_kernel_timing = false; // BayesW: HIP events around every k_bw_sums launch (bench.py's roofline leg)
     int32_t* cass = nullptr;
     double* tables = nullptr; // 4 * G*K
     uint32_t* mt = nullptr;
@@ -1023,6 +1025,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         h->p2p_enabled = value != 0;
     } else if (!std::strcmp(name, "force_split")) {
         h->force_split = value != 0;
+    } else if (!std::strcmp(name, "w_kernel_timing")) {
+        h->w_kernel_timing = value != 0;
     } else if (!std::strcmp(name, "debug_timing")) {
         h->debug_timing = value != 0;
     } else if (!std::strcmp(name, "chunk")) {

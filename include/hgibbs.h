@@ -209,7 +209,8 @@ typedef struct {
     uint64_t launches;    /* batch launches of the last sweep */
     uint64_t nnz_updates; /* markers whose effect changed */
     uint64_t ars_draws, ars_evals;
-    double device_ms;
+    double device_ms;       /* first launch to last, host round trips included */
+    double sums_kernel_ms;  /* total of the k_bw_sums launches (option "w_kernel_timing"), else 0 */
 } hgibbs_w_sweep_stats;
 
 /* failure indicator (0/1) of the n_global kept individuals; allocates vi next to eps */

@@ -17,8 +17,22 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def main_bayesw(sample, lib_name):
+    import orc
+    L = orc.load(lib_name)
+    d = np.load(sample)
+    ch = orc.BwChain(L, d["bed"], int(d["N"]), d["y"], d["fail"], mS=d["mS"], seed=1222, shuffle=1, quad=int(d["quad"]))
+    ch.iterate()
+    t0 = time.perf_counter()
+    ch.iterate()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"markers_per_s": d["bed"].shape[0] / dt, "seconds": dt, "lib": lib_name, "threads": 1}))
+
+
 def main():
     sample, lib_name, threads = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4] == "bayesw":
+        return main_bayesw(sample, lib_name)
     if lib_name == "liboracle_omp.so":  # build for THIS host's CPU
         subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "--quiet",
                                os.path.join(ROOT, "oracle", "liboracle_omp.so")])
