@@ -52,6 +52,25 @@ def from_reference():
         print("dotp_lut.npz from", mk)
 
 
+EXAMPLE_FILES = ["t_M10K_N_5K.fam", "t_M10K_N_5K.bim", "t_M10K_N_5K.dim", "normal.phen", "normal.group", "normal.mS", "normal.h2",
+                 "Weibull.phen", "Weibull.fail", "Weibull.h2"]
+
+
+def example_inputs():
+    """The input files of the reference's shipped example (data, not code): sample and variant lists,
+    the two phenotype files, the failure indicator, the group / mixture files of BASELINE configs 1, 3
+    and 5.  The genotype file example/t_M10K_N_5K.bed itself is not in the checkout."""
+    import shutil
+    src = os.path.join(REF, "example")
+    if not os.path.isdir(src):
+        return
+    dst = os.path.join(GOLD, "example")
+    os.makedirs(dst, exist_ok=True)
+    for f in EXAMPLE_FILES:
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    print("example inputs copied to", dst)
+
+
 def from_oracle():
     import ctypes as C
     import orc
@@ -150,4 +169,5 @@ def from_oracle():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     from_reference()
+    example_inputs()
     from_oracle()
