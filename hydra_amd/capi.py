@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hgibbs_w_reduce", "hgibbs_w_refresh_vi", "hgibbs_w_get_vi", "hgibbs_w_marker_sums", "hgibbs_w_sweep", "hgibbs_w_last_sweep_stats",
     "hgibbs_w_get_beta", "hgibbs_w_set_beta", "hydraw_chain_create", "hydraw_chain_destroy", "hydraw_chain_set_covariates",
     "hydraw_chain_reseed_ars", "hydraw_chain_iterate", "hydraw_chain_state", "hydraw_chain_gamma", "hydraw_chain_order",
-    "hydraw_chain_last_nnz", "hydraw_chain_csv_line",
+    "hydraw_chain_last_nnz", "hydraw_chain_csv_line", "hydraw_chain_restore",
 ]
 
 
@@ -59,6 +59,13 @@ class WSweepStats(C.Structure):
 class WModelDesc(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("shuffle", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("groups", C.POINTER(C.c_int32)), ("mS", C.POINTER(C.c_double)), ("quad_points", C.c_int32)]
+
+
+class WRestartState(C.Structure):
+    _fields_ = [("iteration", C.c_uint32), ("mu", C.c_double), ("alpha", C.c_double), ("sigmaG", C.POINTER(C.c_double)),
+                ("pi", C.POINTER(C.c_double)), ("beta", C.POINTER(C.c_double)), ("components", C.POINTER(C.c_int32)),
+                ("eps", C.POINTER(C.c_double)), ("order", C.POINTER(C.c_int32)), ("gamma", C.POINTER(C.c_double)),
+                ("xI", C.POINTER(C.c_int32)), ("rng", RngState), ("ars_seed", C.c_uint32)]
 
 
 LOGDENS_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
@@ -161,6 +168,7 @@ def lib():
     L.hydraw_chain_last_nnz.argtypes = [vp]
     L.hydraw_chain_last_nnz.restype = C.c_uint64
     L.hydraw_chain_csv_line.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.hydraw_chain_restore.argtypes = [vp, C.POINTER(WRestartState)]
     L.hydra_chain_last_nnz.restype = C.c_uint64
     _lib = L
     return L
@@ -534,6 +542,30 @@ class BwChain:
 
     def reseed_ars(self, seed):
         check(self.L.hydraw_chain_reseed_ars(self.h, seed))
+
+    def rng_words(self):
+        st = self.state()
+        rng = RngState()
+        rng.x[:] = list(st["rng_x"])
+        rng.idx = st["rng_idx"]
+        out = np.zeros(624, dtype=np.uint32)
+        check(self.L.hydra_rng_to_boost_words(C.byref(rng), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def restore(self, iteration, mu, alpha, sigmaG, pi, beta, components, eps, order, rng_words, ars_seed, gamma=None, xI=None):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = [f64(sigmaG), f64(pi), f64(beta), i32(components), f64(eps), i32(order)]
+        st = WRestartState()
+        st.iteration, st.mu, st.alpha, st.ars_seed = iteration, mu, alpha, ars_seed
+        st.sigmaG, st.pi, st.beta = _dp(keep[0]), _dp(keep[1]), _dp(keep[2])
+        st.components, st.eps, st.order = _ip(keep[3]), _dp(keep[4]), _ip(keep[5])
+        if gamma is not None:
+            keep += [f64(gamma), i32(xI)]
+            st.gamma, st.xI = _dp(keep[6]), _ip(keep[7])
+        w = np.ascontiguousarray(rng_words, dtype=np.uint32)
+        check(self.L.hydra_rng_from_boost_words(w.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st.rng)))
+        check(self.L.hydraw_chain_restore(self.h, C.byref(st)))
 
     def iterate(self):
         check(self.L.hydraw_chain_iterate(self.h))

@@ -13,7 +13,7 @@
 // `--mpibayes bayesWMPI --failure F --quad_points Q` runs BayesW (src/BayesW.cpp:905) on one GPU.
 //
 // Not reproduced (out of scope for the hot path): sparse
-// file formats, bayesFH, marker-sharded MPI, the .lst/tarball, --restart for bayesWMPI.
+// file formats, bayesFH, marker-sharded MPI, the .lst/tarball.
 // Multi-GPU: one process per GPU (RANK/WORLD_SIZE/LOCAL_RANK in the
 // environment, as torchrun/mpirun export them); individuals are sharded and the
 // ncclUniqueId travels through a file in --mcmc-out-dir.
@@ -441,7 +441,6 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
     if (nranks > 1) fatal("FATAL  : bayesWMPI runs on one GPU in this build");
     if (opt.failureFile.empty()) fatal("FATAL  : --failure is mandatory with --mpibayes bayesWMPI");
     if (opt.quad_points.empty()) fatal("Possible number of quad_points = 3,5,7,9,11,13,15,17,25"); // src/BayesW.cpp:706-708
-    if (opt.restart) fatal("FATAL  : --restart is not available for bayesWMPI in this build");
     const int quad = std::atoi(opt.quad_points.c_str());
     std::vector<std::string> fam_ids;
     const size_t numInds = count_fam(opt.bedFile + ".fam", &fam_ids);
@@ -488,7 +487,8 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
     struct stat sb;
     if (stat(opt.mcmcOutDir.c_str(), &sb) != 0)
         if (std::system(("mkdir -p " + opt.mcmcOutDir).c_str()) != 0) fatal("FATAL  : can not create --mcmc-out-dir");
-    const std::string base = opt.mcmcOutDir + "/" + opt.mcmcOutNam;
+    const std::string base_in = opt.mcmcOutDir + "/" + opt.mcmcOutNam; // a restart reads <name>.*, writes <name>_rs.* (:994-1008)
+    const std::string base = opt.restart ? base_in + "_rs" : base_in;
 
     hgibbs_t dev = nullptr;
     hg_check(hgibbs_create(local_rank, &dev), "hgibbs_create");
@@ -523,6 +523,91 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
     hg_check(hydraw_chain_create(dev, &md, y.data(), fail.data(), &chain), "hydraw_chain_create");
     if (opt.covariates) hg_check(hydraw_chain_set_covariates(chain, covX.data(), C), "hydraw_chain_set_covariates");
 
+    // ---- --restart: BayesW::init_from_restart, src/BayesW.cpp:869-903 (readers src/data.cpp:523-663) ----
+    unsigned iteration_start = 0;
+    if (opt.restart) {
+        std::printf("RESTART: from files: %s.* files\n", base_in.c_str());
+        std::ifstream file(base_in + ".csv");
+        if (!file) fatal("*FATAL*: failed to open csv file " + base_in + ".csv!");
+        unsigned it_from = 0, first_thinned = 0;
+        int nSaved = 0, nThinned = 0;
+        double r_mu = 0.0, r_alpha = 0.0;
+        std::vector<double> r_sigmaG(G), r_pi((size_t)G * K);
+        std::string str;
+        while (std::getline(file, str)) {
+            if (str.empty()) continue;
+            for (char& ch : str)
+                if (ch == ',') ch = ' ';
+            char* q = &str[0];
+            const long it = std::strtol(q, &q, 10);
+            if (it % opt.thin != 0) fatal("FATAL  : " + base_in + ".csv: iteration " + std::to_string(it) + " is not a multiple of --thin");
+            if (++nThinned == 1) first_thinned = (unsigned)it;
+            if (it % opt.save != 0) continue;
+            ++nSaved;
+            it_from = (unsigned)it;
+            r_mu = std::strtod(q, &q);
+            (void)std::strtod(q, &q); // sigmaG.sum()
+            r_alpha = std::strtod(q, &q);
+            (void)std::strtod(q, &q); // h2
+            (void)std::strtol(q, &q, 10); // m0
+            const long rows = std::strtol(q, &q, 10), cols = std::strtol(q, &q, 10);
+            if (rows != G || cols != K) fatal("FATAL  : " + base_in + ".csv: pi is " + std::to_string(rows) + "x" + std::to_string(cols) + ", expected " + std::to_string(G) + "x" + std::to_string(K));
+            for (int g = 0; g < G; ++g) r_sigmaG[g] = std::strtod(q, &q);
+            for (size_t i = 0; i < (size_t)G * K; ++i) r_pi[i] = std::strtod(q, &q);
+        }
+        if (nSaved == 0) fatal("FATAL  : No saved iteration could be found when reading " + base_in + ".csv!");
+        if (it_from == 0) fatal("FATAL  : There is no point in restarting a chain from iteration 0 (not saved anyway)\n         => restart your analysis from scratch");
+        const bool xf = opt.useXfilesInRestart;
+        std::vector<double> r_beta(Mtot);
+        std::vector<int32_t> r_comp(Mtot);
+        read_marker_history(base_in + (xf ? ".xbet" : ".bet"), xf, Mtot, it_from, first_thinned, opt.thin, sizeof(double), r_beta.data());
+        read_marker_history(base_in + (xf ? ".xcpn" : ".cpn"), xf, Mtot, it_from, first_thinned, opt.thin, sizeof(int32_t), r_comp.data());
+        unsigned len = 0;
+        std::vector<uint8_t> eb = read_dump(base_in + ".eps." + std::to_string(rank), it_from, sizeof(double), &len);
+        expect_u(len, Ntot, ".eps Ntot");
+        std::vector<uint8_t> mb = read_dump(base_in + ".mrk." + std::to_string(rank), it_from, sizeof(int32_t), &len);
+        expect_u(len, Mtot, ".mrk M");
+        std::vector<double> r_gamma(C);
+        std::vector<uint8_t> xb;
+        if (opt.covariates) { // text .gam: the last line whose iteration is a multiple of --save (src/data.cpp:624-663)
+            std::ifstream gf(base_in + ".gam");
+            if (!gf) fatal("*FATAL*: failed to open csv file " + base_in + ".gam!");
+            long g_it = -1;
+            while (std::getline(gf, str)) {
+                if (str.empty()) continue;
+                for (char& ch : str)
+                    if (ch == ',') ch = ' ';
+                char* q = &str[0];
+                const long it = std::strtol(q, &q, 10);
+                if (it % opt.save != 0) continue;
+                g_it = it;
+                for (int i = 0; i < C; ++i) r_gamma[i] = std::strtod(q, &q);
+            }
+            expect_u((unsigned)g_it, it_from, ".gam iteration");
+            xb = read_dump(base_in + ".xiv", it_from, sizeof(int32_t), &len);
+            expect_u(len, (unsigned)C, ".xiv length");
+        }
+        hydraw_restart_state rs{};
+        rs.iteration = it_from;
+        rs.mu = r_mu;
+        rs.alpha = r_alpha;
+        rs.sigmaG = r_sigmaG.data();
+        rs.pi = r_pi.data();
+        rs.beta = r_beta.data();
+        rs.components = r_comp.data();
+        rs.eps = (const double*)eb.data();
+        rs.order = (const int32_t*)mb.data();
+        rs.gamma = opt.covariates ? r_gamma.data() : nullptr;
+        rs.xI = opt.covariates ? (const int32_t*)xb.data() : nullptr;
+        rs.ars_seed = opt.seed + it_from; // srand(opt.seed + iteration_to_restart_from), :877
+        read_rng_file(base_in + ".rng." + std::to_string(rank), &rs.rng);
+        hg_check(hydraw_chain_restore(chain, &rs), "hydraw_chain_restore");
+        iteration_start = it_from + 1;
+        std::printf("INFO   : %s\nINFO   : RESTART DETECTED\nINFO   : restarting from: %s.* files\n", std::string(100, '*').c_str(), base_in.c_str());
+        std::printf("INFO   : last saved iteration:        %d\nINFO   : will restart from iteration: %d\nINFO   : %s\n", it_from, iteration_start,
+                    std::string(100, '*').c_str());
+    }
+
     auto open_trunc = [&](const std::string& p) {
         FILE* f = std::fopen(p.c_str(), "wb+");
         if (!f) fatal("FATAL  : can not create " + p);
@@ -544,7 +629,7 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
     std::vector<char> buff(50000);
     unsigned n_thinned_saved = 0;
     const double t_all = now_s();
-    for (unsigned iteration = 0; iteration < opt.chainLength; ++iteration) {
+    for (unsigned iteration = iteration_start; iteration < opt.chainLength; ++iteration) {
         const double t0 = now_s();
         hg_check(hydraw_chain_iterate(chain), "hydraw_chain_iterate");
         const double t1 = now_s();

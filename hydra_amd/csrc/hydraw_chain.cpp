@@ -196,6 +196,33 @@ int hydraw_chain_reseed_ars(hydraw_chain_t c, uint32_t seed)
     return 0;
 }
 
+int hydraw_chain_restore(hydraw_chain_t c, const hydraw_restart_state* st)
+{
+    if (!c || !st || !st->sigmaG || !st->pi || !st->beta || !st->components || !st->eps || !st->order)
+        return wfail("hydraw_chain_restore: null argument");
+    if (c->C > 0 && (!st->gamma || !st->xI)) return wfail("hydraw_chain_restore: covariates set but no gamma/xI given");
+    const int G = c->G, K = c->K;
+    for (uint32_t i = 0; i < c->M; ++i)
+        if (st->order[i] < 0 || (uint32_t)st->order[i] >= c->M) return wfail("hydraw_chain_restore: marker index out of range");
+    c->mu = st->mu;
+    c->alpha = st->alpha;
+    std::copy(st->sigmaG, st->sigmaG + G, c->sigmaG.begin());
+    std::copy(st->pi, st->pi + (size_t)G * K, c->pi.begin());
+    std::copy(st->order, st->order + c->M, c->order.begin());
+    for (int i = 0; i < c->C; ++i) {
+        c->gamma[i] = st->gamma[i];
+        c->xI[i] = (unsigned)st->xI[i];
+    }
+    c->sumSigmaG = 0.0; // :1018
+    for (int g = 0; g < G; ++g) c->sumSigmaG += c->sigmaG[g];
+    c->rng = st->rng;
+    hgibbs_grand_seed(&c->grand, st->ars_seed);
+    if (hgibbs_w_set_beta(c->dev, st->beta, st->components)) return 1;
+    if (hgibbs_set_residual(c->dev, st->eps)) return 1;
+    c->iteration = st->iteration + 1;
+    return 0;
+}
+
 int hydraw_chain_iterate(hydraw_chain_t c)
 {
     if (!c) return wfail("hydraw_chain_iterate: null chain");

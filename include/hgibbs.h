@@ -261,6 +261,23 @@ int hydraw_chain_gamma(hydraw_chain_t c, double* gamma_out, int32_t* xI_out);
 const int32_t* hydraw_chain_order(hydraw_chain_t c);
 uint64_t hydraw_chain_last_nnz(hydraw_chain_t c);
 int hydraw_chain_csv_line(hydraw_chain_t c, uint32_t iteration, char* buf, size_t len);
+/* BayesW::init_from_restart (src/BayesW.cpp:869-903) + :1300-1311: the regular init, then the dumped
+ * state; the ARS stream restarts at srand(ars_seed) (the reference passes opt.seed + iteration, :877) */
+typedef struct {
+    uint32_t iteration;
+    double mu, alpha;
+    const double* sigmaG;      /* G */
+    const double* pi;          /* G*K */
+    const double* beta;        /* M */
+    const int32_t* components; /* M */
+    const double* eps;         /* n_global */
+    const int32_t* order;      /* M */
+    const double* gamma;       /* C or NULL */
+    const int32_t* xI;         /* C or NULL */
+    hgibbs_rng_state rng;
+    uint32_t ars_seed;
+} hydraw_restart_state;
+int hydraw_chain_restore(hydraw_chain_t c, const hydraw_restart_state* st);
 
 /* ---- checkpoint / restart (src/BayesRRm.cpp:842-928, :2802-2838) --------- */
 /* State a --restart run reads back from the dump files; arrays are host

@@ -520,6 +520,31 @@ int orc_bw_iterate(orc_bw* c)
     return 0;
 }
 
+/* BayesW::init_from_restart (src/BayesW.cpp:869-903) and the restart branch of runMpiGibbs_bW
+ * (:1300-1311, :1018): dumped state over the regular init, srand(ars_seed) */
+void orc_bw_restore(orc_bw* c, double mu, double alpha, const double* sigmaG, const double* pi, const double* beta, const int* components,
+                    const double* eps, const int* order, const double* gamma, const int* xI, const uint32_t* rng_words, uint32_t ars_seed)
+{
+    c->mu = mu;
+    c->alpha = alpha;
+    for (int g = 0; g < c->G; ++g) c->sigmaG[g] = sigmaG[g];
+    for (int i = 0; i < c->G * c->K; ++i) c->pi[i] = pi[i];
+    for (uint32_t i = 0; i < c->M; ++i) {
+        c->beta[i] = beta[i];
+        c->components[i] = components[i];
+        c->order[i] = order[i];
+    }
+    for (uint32_t i = 0; i < c->N; ++i) c->eps[i] = eps[i];
+    for (int i = 0; i < c->C; ++i) {
+        c->gamma[i] = gamma[i];
+        c->xI[i] = (unsigned)xI[i];
+    }
+    c->sumSigmaG = 0.0;
+    for (int g = 0; g < c->G; ++g) c->sumSigmaG += c->sigmaG[g];
+    orc_mt_load_words(&c->rng, rng_words);
+    srand(ars_seed);
+}
+
 double* orc_bw_beta(orc_bw* c) { return c->beta.data(); }
 int* orc_bw_components(orc_bw* c) { return c->components.data(); }
 double* orc_bw_eps(orc_bw* c) { return c->eps.data(); }

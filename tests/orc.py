@@ -207,6 +207,9 @@ def _bind_bw(L):
     L.orc_bw_set_arms.argtypes = [vp, vp]
     L.orc_bw_set_covariates.argtypes = [vp, dp, C.c_int]
     L.orc_bw_reseed_ars.argtypes = [vp, C.c_uint32]
+    L.orc_bw_restore.argtypes = [vp, C.c_double, C.c_double, dp, dp, dp, ip, dp, ip, dp, ip, C.POINTER(C.c_uint32), C.c_uint32]
+    L.orc_bw_restore.restype = None
+    L.orc_rng_print_words.argtypes = [C.POINTER(OrcMt), C.POINTER(C.c_uint32)]
     L.orc_bw_iterate.argtypes = [vp]
     L.orc_bw_quad_supported.argtypes = [C.c_int]
     for f in ("beta", "eps", "vi", "sigmaG", "pi", "mave", "msd", "sum_failure", "gamma"):
@@ -278,6 +281,23 @@ class BwChain:
 
     def reseed_ars(self, seed):
         self.L.orc_bw_reseed_ars(self.h, seed)
+
+    def rng_words(self):
+        out = np.zeros(624, dtype=np.uint32)
+        self.L.orc_rng_print_words(self.L.orc_bw_rng(self.h), p(out, C.c_uint32))
+        return out
+
+    def xI(self):
+        return np.ctypeslib.as_array(self.L.orc_bw_xI(self.h), shape=(self.C,)).astype(np.int32)
+
+    def restore(self, mu, alpha, sigmaG, pi, beta, components, eps, order, rng_words, ars_seed, gamma=None, xI=None):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        k = [f64(sigmaG), f64(pi), f64(beta), i32(components), f64(eps), i32(order),
+             f64(gamma if gamma is not None else np.zeros(1)), i32(xI if xI is not None else np.zeros(1)),
+             np.ascontiguousarray(rng_words, dtype=np.uint32)]
+        self.L.orc_bw_restore(self.h, mu, alpha, dptr(k[0]), dptr(k[1]), dptr(k[2]), iptr(k[3]), dptr(k[4]), iptr(k[5]), dptr(k[6]), iptr(k[7]),
+                              p(k[8], C.c_uint32), ars_seed)
 
     def iterate(self):
         err = self.L.orc_bw_iterate(self.h)

@@ -204,3 +204,39 @@ def test_quadrature_orders(oracle):
         out[n] = ml[1]
     assert abs(out[3] / out[9] - 1) < 1e-3 and abs(out[5] / out[9] - 1) < 1e-5 and abs(out[7] / out[9] - 1) < 1e-7
     assert abs(out[11] / out[9] - 1) > 1e-2 and abs(out[25] / out[9] - 1) < 1e-8
+
+
+@pytest.mark.parametrize("with_cov", [False, True])
+def test_oracle_bayesw_restore_is_exact(oracle, with_cov):
+    """A checkpoint (state + srand(seed + iteration), src/BayesW.cpp:2029) restored into a fresh chain
+    (init_from_restart, :869-903, srand(seed + iteration) again, :877) continues the uninterrupted chain."""
+    _, bed, y, fail, _ = _case(M=120, N=500, seed=21)
+    X = np.random.default_rng(2).normal(size=(500, 2)) * 0.2
+    seed = 9
+
+    def fresh(s):
+        c = orc.BwChain(oracle, bed, 500, y, fail, seed=s, quad=7)
+        if with_cov:
+            c.set_covariates(X)
+        return c
+
+    a = fresh(seed)
+    for _ in range(4):
+        a.iterate()
+    a.reseed_ars(seed + 3)
+    snap = dict(mu=a.mu, alpha=a.alpha, sigmaG=a.arr("sigmaG").copy(), pi=a.arr("pi").copy(), beta=a.arr("beta").copy(),
+                components=a.arr("components").copy(), eps=a.arr("eps").copy(), order=a.arr("order").copy(), rng_words=a.rng_words(),
+                ars_seed=seed + 3)
+    if with_cov:
+        snap.update(gamma=a.arr("gamma").copy(), xI=a.xI())
+    want = []
+    for it in range(4, 7):
+        a.iterate()
+        want.append((a.arr("beta").copy(), a.arr("components").copy(), a.arr("eps").copy(), a.mu, a.alpha, a.csv_line(it)))
+    b = fresh(777)
+    b.restore(**snap)
+    for it in range(4, 7):
+        b.iterate()
+        w = want[it - 4]
+        assert np.array_equal(b.arr("beta"), w[0]) and np.array_equal(b.arr("components"), w[1]) and np.array_equal(b.arr("eps"), w[2])
+        assert b.mu == w[3] and b.alpha == w[4] and b.csv_line(it) == w[5]

@@ -258,3 +258,98 @@ def test_cli_bayesw_refuses_bad_options(tmp_path):
     assert r.returncode != 0 and "Possible number of quad_points = 3,5,7,9,11,13,15,17,25" in r.stderr
     r = subprocess.run(base + ["--failure", prefix + ".fail"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "Possible number of quad_points" in r.stderr
+
+
+# ---- checkpoint / restart (src/BayesW.cpp:869-903, :2028-2052) --------------------------------------
+def test_bayesw_restore_continues_the_chain(oracle):
+    M, N, seed = 160, 1100, 13
+    _, bed, y, fail = make_case(M, N, seed=51)
+    X = np.random.default_rng(6).normal(size=(N, 2)) * 0.2
+
+    def fresh(s):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        ch = capi.BwChain(dev, y, fail, seed=s, quad=9)
+        ch.set_covariates(X)
+        return dev, ch
+
+    dev_a, a = fresh(seed)
+    for _ in range(4):
+        a.iterate()
+    a.reseed_ars(seed + 3)
+    st = a.state()
+    beta, comp = a.beta()
+    g, xi = a.gamma()
+    snap = dict(iteration=3, mu=st["mu"], alpha=st["alpha"], sigmaG=st["sigmaG"], pi=st["pi"], beta=beta, components=comp,
+                eps=dev_a.get_residual(), order=a.order(), rng_words=a.rng_words(), ars_seed=seed + 3, gamma=g, xI=xi)
+    dev_b, b = fresh(999)
+    b.restore(**snap)
+    ref = orc.BwChain(oracle, bed, N, y, fail, seed=1, quad=9)
+    ref.set_covariates(X)
+    osnap = {k: v for k, v in snap.items() if k != "iteration"}
+    ref.restore(**osnap)
+    want = []
+    for it in range(4, 8):
+        ref.iterate()
+        want.append((ref.arr("beta").copy(), ref.arr("components").copy(), ref.mu))
+    for it in range(4, 8):
+        a.iterate()
+        b.iterate()
+        ba, ca = a.beta()
+        bb, cb = b.beta()
+        assert np.array_equal(ba, bb) and np.array_equal(ca, cb) and np.array_equal(dev_a.get_residual(), dev_b.get_residual())
+        assert a.csv_line(it) == b.csv_line(it)
+        w = want[it - 4]
+        assert np.array_equal(cb, w[1]) and close(bb, w[0]) and close(b.state()["mu"], w[2])
+
+
+def test_cli_bayesw_restart_from_dump_files(oracle, tmp_path):
+    M, N, seed = 80, 600, 17
+    geno, bed, y, fail = make_case(M, N, seed=61)
+    X = np.random.default_rng(4).normal(size=(N, 2)) * 0.2
+    prefix, out = str(tmp_path / "d"), str(tmp_path / "o")
+    synth.write_plink(prefix, bed, N, y=y)
+    np.savetxt(prefix + ".fail", fail, fmt="%d")
+    with open(prefix + ".cov", "w") as f:
+        for i in range(N):
+            f.write("fam%d ind%d %r %r\n" % (i, i, float(X[i, 0]), float(X[i, 1])))
+    base = [EXE, "--mpibayes", "bayesWMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--failure", prefix + ".fail", "--quad_points", "9",
+            "--covariates", prefix + ".cov", "--mcmc-out-dir", out, "--mcmc-out-name", "w", "--number-individuals", str(N),
+            "--number-markers", str(M), "--thin", "1", "--save", "3", "--seed", str(seed), "--S", "0.001,0.01"]
+    r = subprocess.run(base + ["--chain-length", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(base + ["--chain-length", "9", "--restart"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "will restart from iteration: 4" in r.stdout
+    # the oracle restored from the very same files, the way init_from_restart reads them
+    csv3 = [float(x) for x in open(out + "/w.csv").read().splitlines()[3].split(",")]
+    assert csv3[0] == 3 and csv3[6:8] == [1, 3]
+    mu, alpha, sigmaG, pi = csv3[1], csv3[3], csv3[8:9], csv3[9:12]
+
+    def dump(path, dtype):
+        raw = open(path, "rb").read()
+        it, n = struct.unpack("<II", raw[:8])
+        return it, np.frombuffer(raw[8:8 + n * np.dtype(dtype).itemsize], dtype=dtype)
+
+    it_e, eps = dump(out + "/w.eps.0", np.float64)
+    it_m, mrk = dump(out + "/w.mrk.0", np.int32)
+    it_x, xiv = dump(out + "/w.xiv", np.int32)
+    assert (it_e, it_m, it_x) == (3, 3, 3)
+    gam = [float(x) for x in open(out + "/w.gam").read().splitlines()[3].split(",")]
+    assert gam[0] == 3
+    xb, xc = open(out + "/w.xbet", "rb").read(), open(out + "/w.xcpn", "rb").read()
+    words = np.array(open(out + "/w.rng.0").read().split(), dtype=np.uint64).astype(np.uint32)
+    ref = orc.BwChain(oracle, bed, N, y, fail, seed=4321, quad=9)
+    ref.set_covariates(X)
+    ref.restore(mu, alpha, sigmaG, pi, np.frombuffer(xb[8:], dtype=np.float64), np.frombuffer(xc[8:], dtype=np.int32), eps, mrk, words,
+                seed + 3, gamma=gam[1:], xI=xiv)
+    its, betas = _read_hist(out + "/w_rs.bet", M, np.float64)
+    _, comps = _read_hist(out + "/w_rs.cpn", M, np.int32)
+    csv = open(out + "/w_rs.csv").read().splitlines()
+    assert its == [4, 5, 6, 7, 8]
+    for k, it in enumerate(its):
+        ref.iterate()
+        assert np.array_equal(comps[k], ref.arr("components")) and close(betas[k], ref.arr("beta"))
+        assert close([float(x) for x in csv[k].split(",")], [float(x) for x in ref.csv_line(it).split(",")])
+        if it % 3 == 0:
+            ref.reseed_ars(seed + it)
