@@ -303,6 +303,7 @@ def main():
     ap.add_argument("--M", type=int, default=0, help="override markers")
     ap.add_argument("--batch", type=int, default=0, help="speculative batch width (0 = library default)")
     ap.add_argument("--cpg", type=int, default=0, help="columns per workgroup column-group")
+    ap.add_argument("--max-seg", type=int, default=0, help="segments (predicted events) one launch may chain through (0 = library default)")
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
                     help="per-batch cross-GPU exchange: in-launch peer mailboxes, RCCL all-reduce, or self-checked choice")
@@ -353,6 +354,8 @@ def main():
         dev.set_option("batch", args.batch)
     if args.cpg:
         dev.set_option("cols_per_group", args.cpg)
+    if args.max_seg:
+        dev.set_option("max_seg", args.max_seg)
 
     t_setup = time.perf_counter()
     dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)

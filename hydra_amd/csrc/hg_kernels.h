@@ -52,7 +52,8 @@ constexpr int S_CAP = 64;                // max tile-group slices (gridDim.x): o
 constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
-constexpr int NROW = 3;                  // rows per batch column: s1, s2, integer Gram term with the pivot
+constexpr int MAX_SEG = 4;               // segments per launch: each ends on a predicted event (its pivot) and hands one pending update on
+constexpr int NROW = NSUM + MAX_SEG - 1; // rows per batch column: s1, s2, integer Gram terms with the pivots of the earlier segments
 constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // partial rows per slice (padded)
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
@@ -60,10 +61,11 @@ constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged 
 struct SweepDesc {
     uint32_t cursor;        // next position in order[]
     uint32_t cur;           // which eps buffer is current
-    int32_t pend_marker[2]; // markers whose eps update is still to be applied (in order), -1 none
-    double pv[2][3];        // their update constants for genotype 0,1,2 (missing gets 0)
-    uint32_t batch;         // columns up to and including the pivot (first predicted event)
-    uint32_t batch2;        // all columns of the next launch; [batch, batch2) is the Gram-corrected extension
+    int32_t pend_marker[MAX_SEG]; // markers whose eps update is still to be applied (in order), -1 none
+    double pv[MAX_SEG][3];        // their update constants for genotype 0,1,2 (missing gets 0)
+    uint32_t seg_end[MAX_SEG];    // plan of the next launch: segment s = columns [seg_end[s-1], seg_end[s]); a segment that is
+                                  // followed by another one ends ON a predicted event (its pivot); later segments' dots get the
+                                  // Gram correction for every earlier pivot
     uint32_t rng_idx;       // MT19937 position (0..624)
     uint32_t error;         // non-zero: 1 logL overflow abort (src/BayesRRm.cpp:1910-1913), 2 rng staging overrun, 3 peer timeout
     uint64_t nnz;           // markers with deltaBeta != 0 so far
@@ -127,7 +129,8 @@ struct SweepParams {
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)
     uint32_t slices_max;     // most tile-group slices a launch may use (<= S_CAP)
-    uint32_t ext_limit;      // longest Gram-corrected extension past the pivot
+    uint32_t ext_limit;      // longest Gram-corrected extension past the first pivot
+    uint32_t max_seg;        // segments a launch may plan (1..MAX_SEG)
     // multi-GPU: when non-null the kernel stops after the local reduction and
     // leaves sums[NROW*MAX_BATCH+1] for the all-reduce; k_sweep_draw continues.
     double* sums_out;

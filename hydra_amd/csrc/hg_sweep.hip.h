@@ -26,6 +26,31 @@ struct LdsGen {
     }
 };
 
+// The few descriptor fields the streaming workgroups need (the whole SweepDesc in scalar
+// registers would crowd out the loop's pointers).
+struct DescHead {
+    uint32_t cursor, cur, rng_idx, error;
+    unsigned long long seq;
+    int32_t pend_marker[MAX_SEG];
+    uint32_t seg_end[MAX_SEG];
+};
+
+__device__ __forceinline__ DescHead load_desc_head(const SweepDesc* g)
+{
+    DescHead d;
+    d.cursor = g->cursor;
+    d.cur = g->cur;
+    d.rng_idx = g->rng_idx;
+    d.error = g->error;
+    d.seq = g->seq;
+#pragma unroll
+    for (int q = 0; q < MAX_SEG; ++q) {
+        d.pend_marker[q] = g->pend_marker[q];
+        d.seg_end[q] = g->seg_end[q];
+    }
+    return d;
+}
+
 // LDS carve-up (dynamic, sized by the host from batch capacity, K and cols_per_group
 // so that the streaming workgroups keep their occupancy):
 struct SweepShared {
@@ -49,7 +74,10 @@ struct SweepShared {
     unsigned char* estage; // BLOCK_WAVES x 8 KiB: eps tile of each wave, filled by LDS-DMA (overlays the tail arrays)
     double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
     double* red;       // 128 doubles: exchange buffer of the tail reduction
-    double* ev;        // 8 doubles: event hand-off between the walk and the rest of the workgroup
+    double* ev;        // 3 per segment: (dbeta, mave, mstd) of the event that ended it
+    double* pvl;       // 3*MAX_SEG: update constants of the pending events (kept out of scalar registers)
+    int32_t* pmk;      // MAX_SEG: markers of the events this launch hands on
+    uint8_t* scanf;    // 2*BLOCK flag bytes of the sweep positions after the cursor (bit 0 predicted event, bit 1 missing calls)
     uint32_t wstride;  // NROW*cpg + 1
     uint32_t bcap;     // batch capacity of this launch
 };
@@ -57,32 +85,32 @@ enum { F_LAST = 0, F_POS = 1, F_P2PTMO = 2, F_NACC = 3, F_STOP = 4, F_FPOS = 5, 
 
 constexpr size_t EPS_STAGE_BYTES = (size_t)BLOCK_WAVES * TILE * sizeof(double); // one wave tile of eps per wave (LDS-DMA target)
 
-__host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K)
+__host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K, int nr)
 {
     size_t n = 0;
-    n += (size_t)(NROW * bcap + 1) * 8;                                                       // tot
+    n += (size_t)(nr * bcap + 1) * 8;                                                       // tot
     n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)4 * bcap * 8;        // thr, muk, logl, bold/mave/mstd/dp
     n += (size_t)2 * bcap * 4 + ((bcap + 15) & ~15u);                                         // marker, grp, ada
     return (n + 15) & ~(size_t)15;
 }
 
-__host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg)
+__host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr)
 {
     size_t n = 0;
-    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 8 * 8 + 32 + 16;
-    n += (size_t)BLOCK_WAVES * (NROW * cpg + 1) * 8;
+    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * MAX_SEG * 8 + 16;
+    n += (size_t)BLOCK_WAVES * (nr * cpg + 1) * 8;
     return (n + 15) & ~(size_t)15;
 }
 
 // fixed region (staged generator / tables / small scratch, live for the whole launch), then a
 // UNION: the streaming loop's eps staging tiles and the last arriver's per-batch arrays
-__host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K)
+__host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K, int nr)
 {
-    const size_t tail = sweep_lds_tail_bytes(bcap, K);
-    return sweep_lds_fixed_bytes(cpg) + (tail > EPS_STAGE_BYTES ? tail : EPS_STAGE_BYTES);
+    const size_t tail = sweep_lds_tail_bytes(bcap, K, nr);
+    return sweep_lds_fixed_bytes(cpg, nr) + (tail > EPS_STAGE_BYTES ? tail : EPS_STAGE_BYTES);
 }
 
-__device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint32_t bcap, uint32_t cpg, int K)
+__device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint32_t bcap, uint32_t cpg, int K, int nr)
 {
     SweepShared sh;
     unsigned char* q = base;
@@ -91,14 +119,17 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
     sh.red = reinterpret_cast<double*>(q); q += 128 * 8;
-    sh.ev = reinterpret_cast<double*>(q); q += 8 * 8;
+    sh.ev = reinterpret_cast<double*>(q); q += 16 * 8;
     sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
     sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
-    sh.wstride = NROW * cpg + 1;
+    sh.scanf = q; q += 2 * BLOCK;
+    sh.pvl = reinterpret_cast<double*>(q); q += 3 * MAX_SEG * 8;
+    sh.pmk = reinterpret_cast<int32_t*>(q); q += 16;
+    sh.wstride = nr * cpg + 1;
     sh.wpart = reinterpret_cast<double*>(q);
-    q = base + sweep_lds_fixed_bytes(cpg);
+    q = base + sweep_lds_fixed_bytes(cpg, nr);
     sh.estage = q; // union starts here
-    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(NROW * bcap + 1) * 8;
+    sh.tot = reinterpret_cast<double*>(q); q += (size_t)(nr * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
@@ -134,7 +165,7 @@ struct MarkerMeta {
     double bold, mave, mstd;
 };
 
-__device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, const SweepDesc& d, uint32_t nb, int tid)
+__device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, const DescHead& d, uint32_t nb, int tid)
 {
     MarkerMeta m{-1, 0, false, false, 0.0, 0.0, 0.0};
     if ((uint32_t)tid < nb) {
@@ -158,7 +189,7 @@ struct PivotScan {
     uint32_t f0, f1;
 };
 
-__device__ __forceinline__ PivotScan load_pivot_scan(const SweepParams& p, const SweepDesc& d, int tid)
+__device__ __forceinline__ PivotScan load_pivot_scan(const SweepParams& p, const DescHead& d, int tid)
 {
     PivotScan s{0u, 0u};
     const uint32_t j0 = d.cursor + (uint32_t)tid, j1 = j0 + BLOCK;
@@ -195,25 +226,30 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
 }
 
 // Posterior + draw + bookkeeping for the markers of this batch, given the reduced
-// sums in sh.tot: rows [3j, 3j+1, 3j+2] = (s1, s2, A) of batch column j, last row
-// = sum of eps.  A_j = sum_i gw_j gw_pivot (integer) for the columns of the
-// EXTENSION [nb1, nb2): those dots were taken before the pivot's (position
-// nb1-1, a predicted event) update and are corrected here once its new effect is
-// known:  x_j'eps_new = x_j'eps_old + dbeta_p * x_j'x_p,
-//         x_j'x_p = mstd_j mstd_p (A_j - N mave_j mave_p)   (columns without missing calls).
+// sums in sh.tot: rows [NROW*j ...] = (s1, s2, A_0, A_1, A_2) of batch column j, last
+// row = sum of eps.  The batch is a chain of up to MAX_SEG segments [nbs[s-1], nbs[s]);
+// segment s < last ends ON a predicted event (its pivot, position nbs[s]-1).  The dots
+// of a later segment were taken before the earlier pivots' updates and are corrected
+// here once those new effects are known:
+//         x_j'eps_new = x_j'eps_old + sum_{q<s} dbeta_q * x_j'x_q,
+//         x_j'x_q = mstd_j mstd_q (A_jq - N mave_j mave_q)   (columns without missing calls),
+// with A_jq = sum_i gw_j gw_q the integer Gram term accumulated by the streaming loop.
 // Runs in ONE workgroup of 256 threads.
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
-__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const SweepDesc& d, uint32_t nb1, uint32_t nb2,
+template <int SEG>
+__device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const DescHead& d, const uint32_t (&nbs)[SEG],
                                                  const SweepShared& sh, const MarkerMeta& mm, const PivotScan& scan)
 {
     const int tid = threadIdx.x;
+    constexpr int NR = NSUM + SEG - 1; // rows per batch column at this tier
     const int K = p.K;
+    const uint32_t nb = nbs[SEG - 1];
     const uint32_t idx0 = d.rng_idx;
     const bool need_next = idx0 + MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
     if (need_next) mt_next_block(sh.mt, tid);
 
     // per-column state -> LDS, dot products from the reduced rows
-    if ((uint32_t)tid < nb2) {
+    if ((uint32_t)tid < nb) {
         sh.marker[tid] = mm.marker;
         sh.grp[tid] = mm.grp;
         sh.ada[tid] = mm.ada ? 1 : 0;
@@ -224,10 +260,13 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
         // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
         // A column without missing calls has s2 == sum of eps, bit for bit
         // (same lanes, same order), so it is not accumulated per column.
-        const double s1 = sh.tot[NROW * tid];
-        const double s2 = mm.miss ? sh.tot[NROW * tid + 1] : sh.tot[NROW * sh.bcap];
+        const double s1 = sh.tot[NR * tid];
+        const double s2 = mm.miss ? sh.tot[NR * tid + 1] : sh.tot[NR * sh.bcap];
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
     }
+    // flags of the sweep positions after the old cursor, for the plan of the next launch
+    sh.scanf[tid] = (uint8_t)scan.f0;
+    sh.scanf[tid + BLOCK] = (uint8_t)scan.f1;
     if (tid == 0) {
         sh.flags[F_POS] = idx0;
         sh.flags[F_NACC] = 0;
@@ -235,23 +274,24 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
     }
     __syncthreads();
 
-    // pending updates handed to the next launch
-    int pend_marker[2] = {-1, -1};
-    double pend_pv[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    // pending updates handed to the next launch: kept in LDS by thread 0 (sh.pvl is free again: the
+    // streaming loop is over), markers in sh.pmk
+    if (tid < MAX_SEG) sh.pmk[tid] = -1;
+    if (tid < 3 * MAX_SEG) sh.pvl[tid] = 0.0;
     int npend = 0;
     unsigned long long nnz_add = 0;
 
-    for (int seg = 0; seg < 2; ++seg) {
-        const uint32_t lo = seg ? nb1 : 0u, hi = seg ? nb2 : nb1;
+    for (int seg = 0; seg < SEG; ++seg) {
+        const uint32_t lo = seg ? nbs[seg - 1] : 0u, hi = nbs[seg];
         if (lo >= hi) break; // uniform
 
         // ---- posterior of [lo, hi), one thread per batch column -----------------
         if ((uint32_t)tid >= lo && (uint32_t)tid < hi && mm.ada) {
             double num = sh.dp[tid];
-            if (seg) { // Gram correction for the pivot's update
-                const double A = sh.tot[NROW * tid + 2];
-                const double xx = mm.mstd * sh.ev[2] * (A - p.n_total * (mm.mave * sh.ev[1]));
-                num += sh.ev[0] * xx;
+            for (int q = 0; q < seg; ++q) { // Gram corrections for the earlier pivots' updates, in order
+                const double A = sh.tot[NR * tid + NSUM + q];
+                const double xx = mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1]));
+                num += sh.ev[3 * q] * xx;
             }
             num += mm.bold * p.n_minus_1;
             double den[MAX_K], lpi[MAX_K], hlg[MAX_K];
@@ -370,9 +410,9 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
                     pos += (uint32_t)__shfl((int)consumed, src, 64);
                     const uint32_t f_err = (uint32_t)__shfl((int)gerr, src, 64);
                     if (lane == 0) {
-                        sh.ev[0] = f_dbeta;
-                        sh.ev[1] = sh.mave[base + f];
-                        sh.ev[2] = sh.mstd[base + f];
+                        sh.ev[3 * seg] = f_dbeta;
+                        sh.ev[3 * seg + 1] = sh.mave[base + f];
+                        sh.ev[3 * seg + 2] = sh.mstd[base + f];
                         sh.flags[F_FPOS] = base + f;
                         sh.flags[F_FMARK] = (uint32_t)f_marker;
                         if (f_err) sh.flags[F_ERR] = f_err;
@@ -390,38 +430,99 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
         // an event: its update is pending for the next launch
         const bool stopped = sh.flags[F_STOP] != 0;
         if (stopped) {
-            const double db = sh.ev[0], av = sh.ev[1], sd = sh.ev[2];
+            const double db = sh.ev[3 * seg], av = sh.ev[3 * seg + 1], sd = sh.ev[3 * seg + 2];
             if (db != 0.0) {
-                pend_marker[npend] = (int)sh.flags[F_FMARK];
-                pend_pv[npend][0] = -(av * sd * db);
-                pend_pv[npend][1] = db * (1.0 - av) * sd;
-                pend_pv[npend][2] = db * (2.0 - av) * sd;
+                if (tid == 0) {
+                    sh.pmk[npend] = (int)sh.flags[F_FMARK];
+                    sh.pvl[3 * npend] = -(av * sd * db);
+                    sh.pvl[3 * npend + 1] = db * (1.0 - av) * sd;
+                    sh.pvl[3 * npend + 2] = db * (2.0 - av) * sd;
+                }
                 ++npend;
                 ++nnz_add;
             }
         }
-        // go on into the extension only if segment 0 ran to its end and ended ON the pivot
-        if (!(seg == 0 && stopped && sh.flags[F_FPOS] == nb1 - 1u && nb2 > nb1)) break;
+        // go on into the next segment only if this one ran to its end and ended ON its last column
+        // (the column the later segments' Gram terms were taken with)
+        if (!(stopped && sh.flags[F_FPOS] == hi - 1u && seg + 1 < SEG && nbs[seg + 1] > hi)) break;
         __syncthreads(); // sh.ev stays valid for the corrections; flags are rewritten by the next walk
     }
 
     // ---- hand the state to the next launch ---------------------------------------
     const uint32_t naccept = sh.flags[F_NACC];
     const uint32_t pos = sh.flags[F_POS];
+    // ---- plan of the next launch (positions relative to the NEW cursor), by wave 0 ------------
+    // segment 0 = up to and including the first predicted event (its pivot); every further
+    // segment = up to and including the next predicted event, as long as the previous pivot's
+    // column and the columns involved have no missing calls (their dots get the Gram
+    // corrections above); a column with missing calls stays out and ends the chain.
+    uint32_t want[MAX_SEG];
+#pragma unroll
+    for (int q = 0; q < MAX_SEG; ++q) want[q] = p.batch_limit;
+    if (tid < WAVE) {
+        const uint32_t cap = p.batch_limit;
+        const uint32_t wnd = 2u * BLOCK - naccept; // flags are known for this many positions
+        unsigned long long mev[MAX_BATCH / WAVE], many[MAX_BATCH / WAVE];
+#pragma unroll
+        for (int c = 0; c < MAX_BATCH / WAVE; ++c) {
+            const uint32_t r = (uint32_t)c * WAVE + (uint32_t)tid;
+            const uint32_t f = (r < wnd && r < cap) ? sh.scanf[naccept + r] : 0u;
+            mev[c] = __ballot((f & 1u) != 0u);
+            many[c] = __ballot(f != 0u);
+        }
+        auto first_set = [&](const unsigned long long (&m)[MAX_BATCH / WAVE], uint32_t from, uint32_t lim) -> uint32_t {
+            for (uint32_t c = from / WAVE; c < (uint32_t)(MAX_BATCH / WAVE); ++c) {
+                unsigned long long w = m[c];
+                if (c == from / WAVE) w &= ~0ull << (from % WAVE);
+                if (w) {
+                    const uint32_t r = c * WAVE + (uint32_t)(__ffsll((long long)w) - 1);
+                    return r < lim ? r : 0xffffffffu;
+                }
+            }
+            return 0xffffffffu;
+        };
+        auto is_event = [&](uint32_t r) -> bool { return (mev[r / WAVE] >> (r % WAVE)) & 1ull; };
+        const uint32_t e0 = first_set(mev, 0u, cap);
+        if (e0 != 0xffffffffu) {
+            want[0] = e0 + 1u;
+            // a pivot whose own column has missing calls cannot be corrected for: (any & ~ev) cannot tell, so read its flag
+            bool chain = p.gram && !(sh.scanf[naccept + e0] & 2u);
+            const uint32_t lim = (want[0] + p.ext_limit < cap) ? want[0] + p.ext_limit : cap;
+            for (int q = 1; q < MAX_SEG; ++q) {
+                want[q] = want[q - 1];
+                if (!chain || q >= SEG || (uint32_t)q >= p.max_seg || want[q - 1] >= lim) {
+                    chain = false;
+                    continue;
+                }
+                const uint32_t e = first_set(many, want[q - 1], lim);
+                if (e == 0xffffffffu) { // no further event in reach: run to the limit, nothing can follow
+                    want[q] = lim;
+                    chain = false;
+                } else if (sh.scanf[naccept + e] & 2u) { // a column with missing calls stays out of the extension
+                    want[q] = e;
+                    chain = false;
+                } else {
+                    (void)is_event;
+                    want[q] = e + 1u;
+                }
+            }
+        }
+    }
     if (tid == 0) {
-        SweepDesc n = d;
+        SweepDesc n = *p.desc; // counters come from memory; only this thread needs them
         n.cursor = d.cursor + naccept;
         if (d.pend_marker[0] >= 0) n.cur = d.cur ^ 1u;
-        for (int q = 0; q < 2; ++q) {
-            n.pend_marker[q] = pend_marker[q];
-            for (int c = 0; c < 3; ++c) n.pv[q][c] = pend_pv[q][c];
+        for (int q = 0; q < MAX_SEG; ++q) {
+            n.pend_marker[q] = sh.pmk[q];
+            for (int c = 0; c < 3; ++c) n.pv[q][c] = sh.pvl[3 * q + c];
         }
-        n.nnz = d.nnz + nnz_add;
+        n.nnz += nnz_add;
         n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
-        n.launches = d.launches + 1;
+        n.launches += 1;
         n.seq = d.seq + 1;
-        n.accepted_sum = d.accepted_sum + naccept;
+        n.accepted_sum += naccept;
         if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
+        for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         *p.desc = n;
         if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
             p.dbg[4] = wall_clock64();
@@ -432,51 +533,6 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Swe
             p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
             p.dbg[12] += naccept;
             p.dbg[15] += 1;
-        }
-    }
-
-    // ---- plan of the next launch ---------------------------------------------------
-    // batch  = up to and including the first predicted event after the new cursor (the pivot);
-    // batch2 = further up to and including the NEXT predicted event, as long as the columns
-    //          involved have no missing calls (their dots get the Gram correction above).
-    {
-        const uint32_t cap = p.batch_limit;
-        const uint32_t q0 = (uint32_t)tid, q1 = (uint32_t)tid + BLOCK; // positions relative to the old cursor
-        uint32_t cand = 0xffffffffu;
-        if ((scan.f0 & 1u) && q0 >= naccept) cand = q0 - naccept;
-        else if ((scan.f1 & 1u) && q1 >= naccept) cand = q1 - naccept;
-        const uint32_t p1 = block_min_u32(sh, cand, tid); // distance of the pivot from the new cursor
-        uint32_t want1 = cap, want2 = cap;
-        if (p1 != 0xffffffffu && p1 + 1u <= cap) {
-            want1 = p1 + 1u;
-            // is the pivot's own column free of missing calls?
-            uint32_t pm = 0xffffffffu;
-            if (q0 == naccept + p1) pm = (scan.f0 >> 1) & 1u;
-            if (q1 == naccept + p1) pm = (scan.f1 >> 1) & 1u;
-            const uint32_t pivot_miss = block_min_u32(sh, pm, tid);
-            // first later position that ends the extension: a predicted event or a column with missing calls
-            uint32_t c2 = 0xffffffffu, c2m = 0u;
-            if (q0 > naccept + p1 && scan.f0) {
-                c2 = q0 - naccept;
-                c2m = (scan.f0 >> 1) & 1u;
-            } else if (q1 > naccept + p1 && scan.f1) {
-                c2 = q1 - naccept;
-                c2m = (scan.f1 >> 1) & 1u;
-            }
-            const uint32_t e = block_min_u32(sh, c2, tid);
-            uint32_t em = 0xffffffffu;
-            if (c2 == e && e != 0xffffffffu) em = c2m;
-            const uint32_t e_miss = block_min_u32(sh, em, tid);
-            if (!p.gram || pivot_miss != 0u) want2 = want1;
-            else if (e == 0xffffffffu) want2 = cap;
-            else want2 = e_miss ? e : e + 1u; // a column with missing calls stays out of the extension
-            if (want2 > want1 + p.ext_limit) want2 = want1 + p.ext_limit;
-            if (want2 > cap) want2 = cap;
-            if (want2 < want1) want2 = want1;
-        }
-        if (tid == 0) {
-            p.desc->batch = want1;
-            p.desc->batch2 = want2;
         }
     }
     __syncthreads();
@@ -535,17 +591,18 @@ __device__ __forceinline__ uint32_t gram16(uint32_t ga, uint32_t gb)
 // the contributions in RANK ORDER so that every GPU gets the same bits.  Two
 // parities: a peer can be at most one batch ahead (it needs my rows of batch
 // b+1 before it can finish b+1).  Bounded spin: returns false on timeout.
-__device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDesc& d, uint32_t nb, const SweepShared& sh)
+template <int NR>
+__device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHead& d, uint32_t nb, const SweepShared& sh)
 {
     const int tid = threadIdx.x;
     const int nr = p.p2p.nranks, me = p.p2p.rank;
-    const uint32_t nrows = NROW * nb + 1;
+    const uint32_t nrows = NR * nb + 1;
     const uint32_t parity = (uint32_t)(d.seq & 1ull);
     const unsigned long long epoch = d.seq + 1ull;
     const size_t slot = (size_t)(parity * MAX_RANKS + (uint32_t)me) * ROWS_CAP;
     for (uint32_t it = tid; it < nrows * (uint32_t)nr; it += BLOCK) {
         const uint32_t dst = it / nrows, rr = it % nrows;
-        const double v = sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr];
+        const double v = sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr];
         __hip_atomic_store(p.p2p.data[dst] + slot + rr, v, HG_RLX_SYSTEM);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -572,7 +629,7 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDe
         double acc = 0.0;
         for (int r = 0; r < nr; ++r)
             acc += __hip_atomic_load(p.p2p.data[me] + (size_t)(parity * MAX_RANKS + (uint32_t)r) * ROWS_CAP + rr, HG_RLX_SYSTEM);
-        sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr] = acc;
+        sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc;
     }
     __syncthreads();
     return true;
@@ -583,25 +640,31 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const SweepDe
 // (4 wave tiles = 4096 individuals each).  Every lane keeps the sums of its
 // columns in registers across all its tiles; one wave/block reduction per
 // launch, then per-slice partial rows for the last arriver.
-template <int CPG>
-__global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(SweepParams p)
+template <int CPG, int SEG>
+__global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
-    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
-    const SweepDesc d = *p.desc;
+    constexpr int NR = NSUM + SEG - 1; // rows per batch column: s1, s2 and one Gram term per earlier pivot
+    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
+    const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
-    const uint32_t nb2 = d.batch2 < remaining ? d.batch2 : remaining; // all columns of this launch
-    const uint32_t nb1 = d.batch < nb2 ? d.batch : nb2;               // ... of which [nb1, nb2) are the extension
-    const uint32_t nb = nb2;
+    uint32_t nbs[SEG]; // cumulative ends of this launch's segments
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) {
+        const uint32_t e = d.seg_end[q] < remaining ? d.seg_end[q] : remaining;
+        nbs[q] = (q && e < nbs[q - 1]) ? nbs[q - 1] : e;
+    }
+    const uint32_t nb = nbs[SEG - 1]; // all columns of this launch
     if ((nb == 0 && !pend) || d.error) return; // whole grid agrees: nothing left to do
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t voff = (uint32_t)lane << 2; // the lane's dword inside a 256-byte column piece; bases stay wave-uniform
     // 1-D grid of slices_max * groups_max workgroups; the ACTIVE ones are the first S * nactive
     // in dispatch order (idle ones behind them leave at once and delay nobody)
     const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
     // slices actually used: keep the active workgroups co-resident (3 per CU at this register
     // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
-    constexpr uint32_t RES = (CPG >= 16) ? 512u : 768u; // co-resident workgroups at this instantiation's register budget
+    constexpr uint32_t RES = (CPG >= 16 || SEG > 2) ? 512u : 768u; // co-resident workgroups at this instantiation's register budget
     const uint32_t S = (RES / nactive) < p.slices_max ? ((RES / nactive) ? RES / nactive : 1u) : p.slices_max;
     if (blockIdx.x >= S * nactive) return;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
@@ -617,36 +680,50 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
     // streaming loop (any of them may turn out to be the last arriver)
     const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
     if (!p.sums_out) stage_rng(p, sh, tid);
+    if (pend && tid < 3 * SEG) sh.pvl[tid] = p.desc->pv[tid / 3][tid % 3];
     const PivotScan scan = p.sums_out ? PivotScan{0u, 0u} : load_pivot_scan(p, d, tid);
     if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
     unsigned long long t_loop = 0ull;
     double a1[CPG], a2[CPG], sall = 0.0;
-    uint32_t ag[CPG]; // integer Gram partial with the pivot column (extension columns only)
+    // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields
+    // (a lane adds at most 64 per tile; the host keeps tiles per lane below 1000): ag01 = pivot 0 | pivot 1 << 16
+    uint32_t ag01[CPG], ag2[CPG];
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         a1[c] = a2[c] = 0.0;
-        ag[c] = 0u;
+        ag01[c] = ag2[c] = 0u;
     }
     const uint8_t* colp[CPG];
     bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
-    bool cgram[CPG]; // wave-uniform: column lies in the extension -> needs its Gram term with the pivot
-    bool any_gram = false;
+    int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
+    int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
         const int marker = nb ? p.order[d.cursor + j] : 0;
         cmiss[c] = nb ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
-        cgram[c] = (c0 + c < nb) && (c0 + c >= nb1) && nb1 > 0;
-        any_gram = any_gram || cgram[c];
-        colp[c] = p.bed + (size_t)marker * p.stride + (lane << 2);
+        int sg = 0;
+#pragma unroll
+        for (int q = 0; q < SEG - 1; ++q) sg += (c0 + c < nb && c0 + c >= nbs[q]) ? 1 : 0;
+        cseg[c] = sg;
+        ng = sg > ng ? sg : ng;
+        colp[c] = p.bed + (size_t)marker * p.stride;
     }
-    const uint8_t* pivp = p.bed + (size_t)(any_gram ? p.order[d.cursor + nb1 - 1] : 0) * p.stride + (lane << 2);
-    const uint8_t* pendp0 = p.bed + (size_t)(pend ? d.pend_marker[0] : 0) * p.stride + (lane << 2);
-    const bool pend1 = d.pend_marker[1] >= 0;
-    const uint8_t* pendp1 = p.bed + (size_t)(pend1 ? d.pend_marker[1] : 0) * p.stride + (lane << 2);
+    const bool any_gram = ng > 0;
+    const uint8_t* pivp[SEG - 1];
+#pragma unroll
+    for (int q = 0; q < SEG - 1; ++q)
+        pivp[q] = p.bed + (size_t)((q < ng && nbs[q] > 0) ? p.order[d.cursor + nbs[q] - 1] : 0) * p.stride;
+    int npend = 0;
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) npend += d.pend_marker[q] >= 0 ? 1 : 0;
+    const uint8_t* pendp[SEG];
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) pendp[q] = p.bed + (size_t)(q < npend ? d.pend_marker[q] : 0) * p.stride;
 
+    if (pend) __syncthreads(); // sh.pvl is staged
     {
         // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces --
         // exactly the permuted eps layout) one tile ahead of the arithmetic; column dwords of the
@@ -659,16 +736,19 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
                                                  (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
         };
-        uint32_t w[CPG], wn[CPG], wpiv = 0, wpivn = 0, wp0 = 0, wp0n = 0, wp1 = 0, wp1n = 0;
+        uint32_t w[CPG], wn[CPG], wpiv[SEG - 1] = {}, wpivn[SEG - 1] = {}, wp[SEG] = {}, wpn[SEG] = {};
         uint32_t tg = slice;
         if (tg < ntg) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             dma_eps(tile);
 #pragma unroll
-            for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8));
-            if (any_gram) wpiv = *reinterpret_cast<const uint32_t*>(pivp + ((size_t)tile << 8));
-            if (pend) wp0 = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tile << 8));
-            if (pend1) wp1 = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tile << 8));
+            for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8) + voff);
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q)
+                if (q < ng) wpiv[q] = *reinterpret_cast<const uint32_t*>(pivp[q] + ((size_t)tile << 8) + voff);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q)
+                if (q < npend) wp[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tile << 8) + voff);
         }
         for (; tg < ntg; tg += S) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
@@ -689,19 +769,25 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
                 const uint32_t tilen = tgn * BLOCK_WAVES + wave;
                 dma_eps(tilen);
 #pragma unroll
-                for (int c = 0; c < CPG; ++c) wn[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tilen << 8));
-                if (any_gram) wpivn = *reinterpret_cast<const uint32_t*>(pivp + ((size_t)tilen << 8));
-                if (pend) wp0n = *reinterpret_cast<const uint32_t*>(pendp0 + ((size_t)tilen << 8));
-                if (pend1) wp1n = *reinterpret_cast<const uint32_t*>(pendp1 + ((size_t)tilen << 8));
+                for (int c = 0; c < CPG; ++c) wn[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tilen << 8) + voff);
+#pragma unroll
+                for (int q = 0; q < SEG - 1; ++q)
+                    if (q < ng) wpivn[q] = *reinterpret_cast<const uint32_t*>(pivp[q] + ((size_t)tilen << 8) + voff);
+#pragma unroll
+                for (int q = 0; q < SEG; ++q)
+                    if (q < npend) wpn[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tilen << 8) + voff);
             }
-            uint32_t gwp = 0;
-            if (any_gram) {
+            uint32_t gwp[SEG - 1];
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) {
                 uint32_t nmp;
-                code_weights(wpiv, gwp, nmp);
+                gwp[q] = 0u;
+                if (q < ng) code_weights(wpiv[q], gwp[q], nmp);
             }
             if (pend) { // the previous launch's event(s), in order
-                apply_update16(wp0, d.pv[0][0], d.pv[0][1], d.pv[0][2], e);
-                if (pend1) apply_update16(wp1, d.pv[1][0], d.pv[1][1], d.pv[1][2], e);
+#pragma unroll
+                for (int q = 0; q < SEG; ++q)
+                    if (q < npend) apply_update16(wp[q], sh.pvl[3 * q], sh.pvl[3 * q + 1], sh.pvl[3 * q + 2], e);
                 if (first_group) store_eps16(eps_out, tile, lane, e);
             }
             if (first_group) {
@@ -731,14 +817,22 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
 #pragma unroll
                     for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
                 }
-                if (cgram[c]) ag[c] += gram16(gw[c], gwp);
+                if (cseg[c] > 0) {
+                    uint32_t g = gram16(gw[c], gwp[0]);
+                    if constexpr (SEG > 2) {
+                        if (cseg[c] > 1) g |= gram16(gw[c], gwp[1]) << 16;
+                        if (cseg[c] > 2) ag2[c] += gram16(gw[c], gwp[SEG > 3 ? 2 : 0]);
+                    }
+                    ag01[c] += g;
+                }
             }
             if (tgn < ntg) {
 #pragma unroll
                 for (int c = 0; c < CPG; ++c) w[c] = wn[c];
-                wpiv = wpivn;
-                wp0 = wp0n;
-                wp1 = wp1n;
+#pragma unroll
+                for (int q = 0; q < SEG - 1; ++q) wpiv[q] = wpivn[q];
+#pragma unroll
+                for (int q = 0; q < SEG; ++q) wp[q] = wpn[q];
             }
         }
         __syncthreads(); // every wave is done with its staging tile: the union region may be reused
@@ -747,37 +841,43 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
             const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
-            const double tg = any_gram ? wave_sum((double)ag[c]) : 0.0; // exact: integers far below 2^53
+            // exact: integers far below 2^53
+            const double g0 = any_gram ? wave_sum((double)(ag01[c] & 0xffffu)) : 0.0;
+            const double g1 = ng > 1 ? wave_sum((double)(ag01[c] >> 16)) : 0.0;
+            const double g2 = ng > 2 ? wave_sum((double)ag2[c]) : 0.0;
             if (lane == 0) {
-                sh.wpart[wave * sh.wstride + NROW * c] = t1;
-                sh.wpart[wave * sh.wstride + NROW * c + 1] = t2;
-                sh.wpart[wave * sh.wstride + NROW * c + 2] = tg;
+                double* wp_ = sh.wpart + wave * sh.wstride + NR * c;
+                wp_[0] = t1;
+                wp_[1] = t2;
+                wp_[2] = g0;
+                if constexpr (NR > 3) wp_[3] = g1;
+                if constexpr (NR > 4) wp_[4] = g2;
             }
         }
         if (first_group) {
             const double t = wave_sum(sall);
-            if (lane == 0) sh.wpart[wave * sh.wstride + NROW * CPG] = t;
+            if (lane == 0) sh.wpart[wave * sh.wstride + NR * CPG] = t;
         }
     }
     __syncthreads();
 
     // block partial = waves 0..3 in order, published write-through (sc1)
     {
-        const uint32_t nrow = NROW * ncol;
+        const uint32_t nrow = NR * ncol;
         for (uint32_t t = tid; t < nrow; t += BLOCK) {
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + (NROW * c0 + t), v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + (NR * c0 + t), v, HG_RLX_AGENT);
         }
         if (first_group && tid == BLOCK - 1) {
-            const uint32_t t = NROW * CPG;
+            const uint32_t t = NR * CPG;
             double v = sh.wpart[t];
             v += sh.wpart[sh.wstride + t];
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + NROW * MAX_BATCH, v, HG_RLX_AGENT);
+            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + NR * MAX_BATCH, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
@@ -803,12 +903,12 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
     // 0..127 sum slices 0..31 of row t, threads 128..255 slices 32..63 (all 32
     // loads in flight); row total = (slices 0..31) + (slices 32..63).
     {
-        const uint32_t nrows = NROW * nb + 1;
+        const uint32_t nrows = NR * nb + 1;
         const uint32_t half = tid >> 7, rl = tid & 127u;
         for (uint32_t rr0 = 0; rr0 < nrows; rr0 += 128) {
             const uint32_t rr = rr0 + rl;
             const bool live = rr < nrows;
-            const uint32_t r = (rr == NROW * nb) ? NROW * MAX_BATCH : rr;
+            const uint32_t r = (rr == NR * nb) ? NR * MAX_BATCH : rr;
             const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
             double v[32];
 #pragma unroll
@@ -819,7 +919,7 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
             if (rr0) __syncthreads(); // previous round's exchange buffer is free again
             if (half == 1) sh.red[rl] = acc;
             __syncthreads();
-            if (live && half == 0) sh.tot[(rr == NROW * nb) ? NROW * sh.bcap : rr] = acc + sh.red[rl];
+            if (live && half == 0) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc + sh.red[rl];
         }
     }
     if (tid == 0) {
@@ -830,44 +930,49 @@ __global__ __launch_bounds__(BLOCK, (CPG <= 8 ? 3 : 2)) void k_sweep_batch(Sweep
     if (p.dbg && tid == 0) p.dbg[2] = wall_clock64();
 
     if (p.p2p.nranks > 1 && !p.sums_out) { // multi-GPU, in-launch exchange
-        if (!p2p_exchange(p, d, nb, sh)) {
+        if (!p2p_exchange<NR>(p, d, nb, sh)) {
             if (tid == 0) {
-                SweepDesc n = d;
-                n.error = 3u;
-                *p.desc = n;
+                p.desc->error = 3u;
             }
             return;
         }
     }
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
-        for (int r = tid; r < NROW * MAX_BATCH + 1; r += BLOCK) {
+        for (int r = tid; r < NR * MAX_BATCH + 1; r += BLOCK) {
             double v = 0.0;
-            if (r < NROW * (int)nb) v = sh.tot[r];
-            if (r == NROW * MAX_BATCH) v = sh.tot[NROW * sh.bcap];
+            if (r < NR * (int)nb) v = sh.tot[r];
+            if (r == NR * MAX_BATCH) v = sh.tot[NR * sh.bcap];
             p.sums_out[r] = v;
         }
         return;
     }
-    sweep_draw_phase(p, d, nb1, nb2, sh, meta, scan);
+    sweep_draw_phase<SEG>(p, d, nbs, sh, meta, scan);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
+template <int SEG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
-    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K);
-    const SweepDesc d = *p.desc;
+    constexpr int NR = NSUM + SEG - 1;
+    const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
+    const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
-    const uint32_t nb2 = d.batch2 < remaining ? d.batch2 : remaining;
-    const uint32_t nb1 = d.batch < nb2 ? d.batch : nb2;
+    uint32_t nbs[SEG];
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) {
+        const uint32_t e = d.seg_end[q] < remaining ? d.seg_end[q] : remaining;
+        nbs[q] = (q && e < nbs[q - 1]) ? nbs[q - 1] : e;
+    }
+    const uint32_t nb2 = nbs[SEG - 1];
     if ((nb2 == 0 && !pend) || d.error) return;
     const MarkerMeta meta = load_marker_meta(p, d, nb2, threadIdx.x);
     const PivotScan scan = load_pivot_scan(p, d, threadIdx.x);
     stage_rng(p, sh, threadIdx.x);
-    for (int r = threadIdx.x; r < NROW * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
-    if (threadIdx.x == 0) sh.tot[NROW * sh.bcap] = p.sums_out[NROW * MAX_BATCH];
+    for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
+    if (threadIdx.x == 0) sh.tot[NR * sh.bcap] = p.sums_out[NR * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase(p, d, nb1, nb2, sh, meta, scan);
+    sweep_draw_phase<SEG>(p, d, nbs, sh, meta, scan);
 }
 
 } // namespace hg

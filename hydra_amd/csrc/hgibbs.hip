@@ -123,6 +123,7 @@ struct hgibbs_ctx {
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
     uint32_t ext_limit = 256;
+    uint32_t max_seg = 2; // segments (predicted events) one launch chains through; 3-4 select the wider kernel tier (measured slower on one GPU)
     bool gram = true; // Gram-corrected continuation past the first predicted event
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
@@ -1016,6 +1017,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "max_seg")) {
+        if (value < 1 || value > MAX_SEG) return fail("hgibbs_set_option: max_seg %lld outside [1,%d]", (long long)value, MAX_SEG);
+        h->max_seg = (uint32_t)value;
     } else if (!std::strcmp(name, "ext_limit")) {
         if (value < 0 || value > MAX_BATCH) return fail("ext_limit must be in [0,%d]", MAX_BATCH);
         h->ext_limit = (uint32_t)value;
@@ -1104,10 +1108,11 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const uint32_t ngroups = (batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
-    d0.pend_marker[0] = d0.pend_marker[1] = -1;
+    for (int q = 0; q < MAX_SEG; ++q) {
+        d0.pend_marker[q] = -1;
+        d0.seg_end[q] = batch; // first launch: one segment, planned blind; its tail plans the rest
+    }
     d0.cur = h->eps_cur;
-    d0.batch = batch;
-    d0.batch2 = batch;
     d0.rng_idx = rng->idx;
     d0.seq = h->batch_seq;
     *h->desc_host = d0;
@@ -1155,7 +1160,20 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
     p.ext_limit = h->ext_limit;
-    const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K);
+    p.max_seg = std::max<uint32_t>(1u, std::min<uint32_t>(h->max_seg, MAX_SEG));
+    // two builds of the kernel: tier 2 (one Gram term, two pending updates: lean registers, 3 workgroups per CU) and
+    // tier 4 (three Gram terms, four pending updates; cols_per_group 4 or 8 only)
+    const int tier = (p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
+    if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
+    const int nr = NSUM + tier - 1;
+    // the Gram partials are 16-bit fields per lane (64 per tile at most): with S >= 768 / (batch / cpg) slices a lane
+    // sees ntg / S tiles -- refuse the chain of segments where that could overflow
+    {
+        const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(h->slices ? h->slices : S_CAP, h->n_pad / BLOCK_IND),
+                                                                           (cpg >= 16 ? 512u : 768u) / std::max<uint32_t>(1u, ngroups)));
+        if (((h->n_pad / BLOCK_IND) + s_min - 1) / s_min > 1000u) p.gram = 0;
+    }
+    const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K, nr);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
     if (h->nranks > 1 && split && !h->comm)
@@ -1180,15 +1198,21 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         const uint32_t remaining = M - std::min(M, dh.cursor);
         int n = h->chunk > 0 ? h->chunk : (int)std::min<double>(2048.0, std::max(8.0, 1.25 * remaining / avg_accept + 2));
         for (int i = 0; i < n; ++i) {
-            switch (cpg) {
-            case 2: k_sweep_batch<2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 4: k_sweep_batch<4><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 8: k_sweep_batch<8><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            default: k_sweep_batch<16><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            if (tier == 4) {
+                if (cpg == 4) k_sweep_batch<4, 4><<<grid, BLOCK, lds, h->stream>>>(p);
+                else k_sweep_batch<8, 4><<<grid, BLOCK, lds, h->stream>>>(p);
+            } else {
+                switch (cpg) {
+                case 2: k_sweep_batch<2, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+                case 4: k_sweep_batch<4, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+                case 8: k_sweep_batch<8, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+                default: k_sweep_batch<16, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+                }
             }
             if (split) {
-                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, NROW * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
-                k_sweep_draw<<<1, BLOCK, lds, h->stream>>>(p);
+                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+                if (tier == 4) k_sweep_draw<4><<<1, BLOCK, lds, h->stream>>>(p);
+                else k_sweep_draw<2><<<1, BLOCK, lds, h->stream>>>(p);
             }
         }
         total_launches += (uint64_t)n;

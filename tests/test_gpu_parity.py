@@ -212,6 +212,36 @@ def test_gram_extension_matches_oracle_and_plain_path(oracle, batch):
         assert fewer, "the extension never saved a launch: it is not being exercised"
 
 
+@pytest.mark.parametrize("max_seg,cpg", [(3, 8), (4, 8), (4, 4)])
+def test_chained_segments_match_the_oracle(oracle, max_seg, cpg):
+    """Up to four segments per launch (the wider kernel tier: three Gram terms per column, four pending
+    updates): same chain as the oracle, fewer launches than the two-segment default once effects are
+    non-zero (predicted events to chain through)."""
+    M, N = 1500, 2048
+    bed, y = make_case(M, N, seed=19, missing_rate=0.0)
+    ref = orc.Chain(oracle, bed, N, y, seed=5)
+    launches = {}
+    for ms in (2, max_seg):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("batch", 256)
+        dev.set_option("cols_per_group", cpg)
+        dev.set_option("max_seg", ms)
+        ch = capi.Chain(dev, y, seed=5)
+        tot = 0
+        for it in range(6):
+            if ms == max_seg:
+                ref.iterate()
+            ch.iterate()
+            tot += dev.sweep_stats()["launches"]
+            if ms == max_seg:
+                beta, comp, _ = dev.get_beta()
+                assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
+                assert close(dev.get_residual(), ref.arr("eps"))
+        launches[ms] = tot
+    assert launches[max_seg] < launches[2]
+
+
 @pytest.mark.parametrize("with_comm", [False, True])
 def test_split_path_equals_fused_path(with_comm):
     """The multi-GPU structure (local sums -> all-reduce -> replicated draw, three

@@ -10,15 +10,18 @@ N, M, G, mS = bench.CONFIGS[cfg]
 if len(sys.argv) > 4: M = int(sys.argv[4])
 slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ext = int(sys.argv[6]) if len(sys.argv) > 6 else -1
+max_seg = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+iters = int(sys.argv[8]) if len(sys.argv) > 8 else 3
 dev = capi.Device(0)
 dev.set_option("batch", batch); dev.set_option("cols_per_group", cpg); dev.set_option("debug_timing", 1)
 if slices: dev.set_option("slices", slices)
 if ext >= 0: dev.set_option("ext_limit", ext)
+if max_seg: dev.set_option("max_seg", max_seg)
 dev.synth_bed(N, M, seed=42)
 y = bench.make_phenotype_on_device(dev, N, M, (0, N), seed=43)
 ch = capi.Chain(dev, y, mS=np.array(mS))
 L = capi.lib(); L.hgibbs_debug_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-for it in range(3):
+for it in range(iters):
     ch.iterate()
     t = (C.c_uint64 * 24)(); L.hgibbs_debug_times(dev.h, t)
     t = [x for x in t]
