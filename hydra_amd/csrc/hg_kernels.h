@@ -123,7 +123,9 @@ struct SweepParams {
     // hand-off
     SweepDesc* desc;
     double* partials;      // [S_CAP][ROWS_CAP], written sc1
-    uint32_t* ticket;
+    double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
+    uint32_t* ticket;      // groups that have published their totals
+    uint32_t* gticket;     // [MAX_BATCH]: per column group, workgroups that have stored their partials
     uint32_t nblk_x;
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)

@@ -883,9 +883,44 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
     __syncthreads();
     const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
+    // Two-level hand-off.  First the S workgroups of one column group: the last of them to arrive sums
+    // that group's rows over the slices in fixed order -- threads 0..127 take slices 0..31 of row t,
+    // threads 128..255 slices 32..63 (all 32 loads in flight; partials is [slice][row], so the loads of
+    // one slice are coalesced), row total = (slices 0..31) + (slices 32..63) -- and publishes the totals.
+    // The reduction thus runs in all groups at once, behind the stragglers of the streaming phase.
     if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(p.gticket + group, 1u, HG_RLX_AGENT);
+        sh.flags[F_LAST] = (t == S - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh.flags[F_LAST]) return;
+    {
+        const uint32_t nrowg = NR * ncol + (first_group ? 1u : 0u); // group 0 also owns the sum of eps
+        const uint32_t half = tid >> 7, rl = tid & 127u;
+        for (uint32_t rr0 = 0; rr0 < nrowg; rr0 += 128) {
+            const uint32_t rr = rr0 + rl;
+            const bool live = rr < nrowg;
+            const uint32_t r = (first_group && rr == NR * ncol) ? NR * MAX_BATCH : NR * c0 + rr;
+            const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = (live && half * 32u + u < S) ? __hip_atomic_load(col + (size_t)u * ROWS_CAP, HG_RLX_AGENT) : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+            if (rr0) __syncthreads(); // previous round's exchange buffer is free again
+            if (half == 1) sh.red[rl] = acc;
+            __syncthreads();
+            if (live && half == 0) __hip_atomic_store(p.totals + r, acc + sh.red[rl], HG_RLX_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // then the groups: the last one to publish runs the draw phase
+    if (tid == 0) {
+        __hip_atomic_store(p.gticket + group, 0u, HG_RLX_AGENT);
         const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, HG_RLX_AGENT);
-        sh.flags[F_LAST] = (t == S * nactive - 1u) ? 1u : 0u;
+        sh.flags[F_LAST] = (t == nactive - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (!sh.flags[F_LAST]) return;
@@ -897,29 +932,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         p.dbg[6] = t_loop;
         p.dbg[7] = t_drain;
     }
-
-    // fixed-order reduction over the S slices.  partials is [slice][row], so a
-    // wave's load of one slice covers 64 consecutive rows (coalesced).  Threads
-    // 0..127 sum slices 0..31 of row t, threads 128..255 slices 32..63 (all 32
-    // loads in flight); row total = (slices 0..31) + (slices 32..63).
     {
         const uint32_t nrows = NR * nb + 1;
-        const uint32_t half = tid >> 7, rl = tid & 127u;
-        for (uint32_t rr0 = 0; rr0 < nrows; rr0 += 128) {
-            const uint32_t rr = rr0 + rl;
-            const bool live = rr < nrows;
-            const uint32_t r = (rr == NR * nb) ? NR * MAX_BATCH : rr;
-            const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = (live && half * 32u + u < S) ? __hip_atomic_load(col + (size_t)u * ROWS_CAP, HG_RLX_AGENT) : 0.0;
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc += v[u];
-            if (rr0) __syncthreads(); // previous round's exchange buffer is free again
-            if (half == 1) sh.red[rl] = acc;
-            __syncthreads();
-            if (live && half == 0) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc + sh.red[rl];
+        for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
+            const bool last = rr == NR * nb;
+            sh.tot[last ? NR * sh.bcap : rr] = __hip_atomic_load(p.totals + (last ? NR * MAX_BATCH : rr), HG_RLX_AGENT);
         }
     }
     if (tid == 0) {

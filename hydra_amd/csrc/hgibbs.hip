@@ -110,7 +110,8 @@ struct hgibbs_ctx {
     SweepDesc* desc = nullptr;
     SweepDesc* desc_host = nullptr; // pinned
     double* partials = nullptr;
-    uint32_t* ticket = nullptr;
+    double* totals = nullptr;
+    uint32_t* ticket = nullptr; // word 0: the launch-wide ticket; words 16.. : one per column group
     double* sums = nullptr;    // 3*MAX_BATCH+1 (multi-GPU exchange buffer)
     double* scratch = nullptr; // reductions
     size_t scratch_n = 0;
@@ -515,8 +516,9 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemcpy(h->zig + 515, HG_ZIG_EXP_Y, 257 * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc)));
     HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
-    HIP_TRY(hipMalloc(&h->ticket, 64));
-    HIP_TRY(hipMemset(h->ticket, 0, 64));
+    HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_BATCH) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
     HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&h->dbg, 24 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 24 * sizeof(unsigned long long)));
@@ -536,7 +538,7 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->ticket, h->sums, h->scratch};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -1098,7 +1100,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->adaV, adaV_host, (size_t)M, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->ticket, 0, 64, h->stream));
+    HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t), h->stream));
     k_gather_meta<<<(M + 255) / 256, 256, 0, h->stream>>>(h->order, h->mave, h->mstd, h->beta, h->groups, h->adaV, h->counts, h->s_mave, h->s_mstd,
                                                        h->s_bold, h->s_ga, M);
     HIP_TRY(hipGetLastError());
@@ -1155,6 +1157,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.desc = h->desc;
     p.partials = h->partials;
     p.ticket = h->ticket;
+    p.gticket = h->ticket + 16;
+    p.totals = h->totals;
     p.nblk_x = h->n_pad / BLOCK_IND;
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
