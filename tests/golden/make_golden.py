@@ -14,6 +14,10 @@ Sources, in order of authority:
       - rng_kat.npz     : first draws of every distribution wrapper, seed 1222
       - chain_small.npz : N=64, M=32, K=4, 10 iterations (+ grouped G=2 variant)
       - dot_cases.npz   : (bed column, eps, mave, mstd) -> (s1, s2, num) cases
+  * example/ : the input files of the reference's shipped example (data, not code)
+
+Lives under tests/ because it drives the oracle: only tests/, smoke() and bench.py's
+cpu_baseline leg may.
 """
 import os
 import re
@@ -23,7 +27,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden")

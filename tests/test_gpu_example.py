@@ -1,6 +1,6 @@
 """BASELINE configs 1, 3 and 5 at their own size on the reference's shipped example inputs
 (tests/golden/example: t_M10K_N_5K.fam/.bim, normal.phen, normal.group/.mS, Weibull.phen/.fail,
-copied by tools/make_golden.py).  The genotype file of the example is not in the reference
+copied by tests/golden/make_golden.py).  The genotype file of the example is not in the reference
 checkout, so a seeded synthetic 5000 x 10000 .bed stands in; everything else is read from the
 reference's own files through the command line, and compared with the oracle."""
 import os
