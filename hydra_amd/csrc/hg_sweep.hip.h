@@ -89,14 +89,21 @@ __host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K, int
 {
     size_t n = 0;
     n += (size_t)(nr * bcap + 1) * 8;                                                       // tot
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)4 * bcap * 8;        // thr, muk, logl, bold/mave/mstd/dp
-    n += (size_t)2 * bcap * 4 + ((bcap + 15) & ~15u);                                         // marker, grp, ada
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)bcap * 8;            // thr, muk, logl, dp
     return (n + 15) & ~(size_t)15;
 }
 
-__host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr)
+// per-column metadata of the batch, staged by every workgroup BEFORE the streaming loop (any of them may
+// turn out to be the last arriver): lives in the fixed region so that it is neither held in registers
+// across the loop nor overlaid by the eps staging tiles
+__host__ __device__ inline size_t sweep_lds_meta_bytes(uint32_t bcap)
 {
-    size_t n = 0;
+    return (size_t)3 * bcap * 8 + (size_t)2 * bcap * 4 + ((bcap + 15) & ~15u); // bold, mave, mstd, marker, grp, ada
+}
+
+__host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr, uint32_t bcap)
+{
+    size_t n = sweep_lds_meta_bytes(bcap);
     n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * MAX_SEG * 8 + 16;
     n += (size_t)BLOCK_WAVES * (nr * cpg + 1) * 8;
     return (n + 15) & ~(size_t)15;
@@ -107,7 +114,7 @@ __host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr)
 __host__ __device__ inline size_t sweep_lds_bytes(uint32_t bcap, uint32_t cpg, int K, int nr)
 {
     const size_t tail = sweep_lds_tail_bytes(bcap, K, nr);
-    return sweep_lds_fixed_bytes(cpg, nr) + (tail > EPS_STAGE_BYTES ? tail : EPS_STAGE_BYTES);
+    return sweep_lds_fixed_bytes(cpg, nr, bcap) + (tail > EPS_STAGE_BYTES ? tail : EPS_STAGE_BYTES);
 }
 
 __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint32_t bcap, uint32_t cpg, int K, int nr)
@@ -126,20 +133,20 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.pvl = reinterpret_cast<double*>(q); q += 3 * MAX_SEG * 8;
     sh.pmk = reinterpret_cast<int32_t*>(q); q += 16;
     sh.wstride = nr * cpg + 1;
-    sh.wpart = reinterpret_cast<double*>(q);
-    q = base + sweep_lds_fixed_bytes(cpg, nr);
+    sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
+    sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.mave = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.mstd = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
+    sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
+    sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
+    sh.ada = q;
+    q = base + sweep_lds_fixed_bytes(cpg, nr, bcap);
     sh.estage = q; // union starts here
     sh.tot = reinterpret_cast<double*>(q); q += (size_t)(nr * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
     sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
-    sh.bold = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
-    sh.mave = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
-    sh.mstd = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.dp = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
-    sh.marker = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
-    sh.grp = reinterpret_cast<int32_t*>(q); q += (size_t)bcap * 4;
-    sh.ada = q;
     sh.bcap = bcap;
     return sh;
 }
@@ -157,45 +164,29 @@ __device__ __forceinline__ void mt_next_block(uint32_t* mt, int tid)
     __syncthreads();
 }
 
-// Per-thread marker metadata for the draw phase; loaded EARLY (before the
-// streaming loop) from the sweep-ordered side arrays: no dependent gather.
-struct MarkerMeta {
-    int marker, grp;
-    bool ada, miss;
-    double bold, mave, mstd;
-};
-
-__device__ __forceinline__ MarkerMeta load_marker_meta(const SweepParams& p, const DescHead& d, uint32_t nb, int tid)
+// Per-column metadata for the draw phase, staged EARLY (before the streaming loop) from the
+// sweep-ordered side arrays into LDS: no dependent gather left for the last arriver.
+// sh.ada bit 0 = adaV, bit 1 = the column has missing calls.
+__device__ __forceinline__ void stage_marker_meta(const SweepParams& p, const DescHead& d, uint32_t nb, int tid, const SweepShared& sh)
 {
-    MarkerMeta m{-1, 0, false, false, 0.0, 0.0, 0.0};
     if ((uint32_t)tid < nb) {
         const uint32_t j = d.cursor + tid;
-        m.marker = p.order[j];
         const int ga = p.s_ga[j];
-        m.grp = ga & 0x0fffffff;
-        m.ada = (ga & 0x40000000) != 0;
-        m.miss = (ga & 0x20000000) != 0;
-        m.bold = p.s_bold[j];
-        m.mave = p.s_mave[j];
-        m.mstd = p.s_mstd[j];
+        sh.marker[tid] = p.order[j];
+        sh.grp[tid] = ga & 0x0fffffff;
+        sh.ada[tid] = (uint8_t)(((ga & 0x40000000) ? 1 : 0) | ((ga & 0x20000000) ? 2 : 0));
+        sh.bold[tid] = p.s_bold[j];
+        sh.mave[tid] = p.s_mave[j];
+        sh.mstd[tid] = p.s_mstd[j];
     }
-    return m;
-}
-
-// Positions (relative to the cursor) t and t + BLOCK of the sweep order: bit 0 = the
-// marker's effect is non-zero at sweep start (it WILL change: a predicted event),
-// bit 1 = its column has missing calls.  Loaded before the streaming loop.
-struct PivotScan {
-    uint32_t f0, f1;
-};
-
-__device__ __forceinline__ PivotScan load_pivot_scan(const SweepParams& p, const DescHead& d, int tid)
-{
-    PivotScan s{0u, 0u};
+    // positions t and t + BLOCK after the cursor: bit 0 = the marker's effect is non-zero at sweep start (it WILL
+    // change: a predicted event), bit 1 = its column has missing calls
     const uint32_t j0 = d.cursor + (uint32_t)tid, j1 = j0 + BLOCK;
-    if (j0 < p.M) s.f0 = (p.s_bold[j0] != 0.0 ? 1u : 0u) | ((p.s_ga[j0] & 0x20000000) ? 2u : 0u);
-    if (j1 < p.M) s.f1 = (p.s_bold[j1] != 0.0 ? 1u : 0u) | ((p.s_ga[j1] & 0x20000000) ? 2u : 0u);
-    return s;
+    uint32_t f0 = 0u, f1 = 0u;
+    if (j0 < p.M) f0 = (p.s_bold[j0] != 0.0 ? 1u : 0u) | ((p.s_ga[j0] & 0x20000000) ? 2u : 0u);
+    if (j1 < p.M) f1 = (p.s_bold[j1] != 0.0 ? 1u : 0u) | ((p.s_ga[j1] & 0x20000000) ? 2u : 0u);
+    sh.scanf[tid] = (uint8_t)f0;
+    sh.scanf[tid + BLOCK] = (uint8_t)f1;
 }
 
 // stage generator + normal tables + hyper tables in LDS (issued early as well)
@@ -238,7 +229,7 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
 template <int SEG>
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const DescHead& d, const uint32_t (&nbs)[SEG],
-                                                 const SweepShared& sh, const MarkerMeta& mm, const PivotScan& scan)
+                                                 const SweepShared& sh)
 {
     const int tid = threadIdx.x;
     constexpr int NR = NSUM + SEG - 1; // rows per batch column at this tier
@@ -249,13 +240,18 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     if (need_next) mt_next_block(sh.mt, tid);
 
     // per-column state -> LDS, dot products from the reduced rows
+    struct {
+        int grp;
+        bool ada, miss;
+        double bold, mave, mstd;
+    } mm{0, false, false, 0.0, 0.0, 0.0};
     if ((uint32_t)tid < nb) {
-        sh.marker[tid] = mm.marker;
-        sh.grp[tid] = mm.grp;
-        sh.ada[tid] = mm.ada ? 1 : 0;
-        sh.bold[tid] = mm.bold;
-        sh.mave[tid] = mm.mave;
-        sh.mstd[tid] = mm.mstd;
+        mm.grp = sh.grp[tid];
+        mm.ada = (sh.ada[tid] & 1) != 0;
+        mm.miss = (sh.ada[tid] & 2) != 0;
+        mm.bold = sh.bold[tid];
+        mm.mave = sh.mave[tid];
+        mm.mstd = sh.mstd[tid];
         // dense BED form of the reference (src/BayesRRm.cpp:1785-1790,1809):
         // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
         // A column without missing calls has s2 == sum of eps, bit for bit
@@ -264,9 +260,6 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         const double s2 = mm.miss ? sh.tot[NR * tid + 1] : sh.tot[NR * sh.bcap];
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
     }
-    // flags of the sweep positions after the old cursor, for the plan of the next launch
-    sh.scanf[tid] = (uint8_t)scan.f0;
-    sh.scanf[tid + BLOCK] = (uint8_t)scan.f1;
     if (tid == 0) {
         sh.flags[F_POS] = idx0;
         sh.flags[F_NACC] = 0;
@@ -321,7 +314,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         // q[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)
         for (uint32_t it = tid; it < (hi - lo) * (uint32_t)(K - 1); it += BLOCK) {
             const uint32_t j = lo + it / (uint32_t)(K - 1), kk = it % (uint32_t)(K - 1);
-            if (!sh.ada[j]) continue;
+            if (!(sh.ada[j] & 1)) continue;
             const double* L = sh.logl + j * K;
             const double base = L[kk];
             bool big = false;
@@ -347,7 +340,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             for (uint32_t base = lo; base < hi && !stopped; base += WAVE) {
                 const uint32_t j = base + lane;
                 const bool valid = j < hi;
-                const bool ada = valid && sh.ada[valid ? j : 0] != 0;
+                const bool ada = valid && (sh.ada[valid ? j : 0] & 1) != 0;
                 const double bold = valid ? sh.bold[j] : 0.0;
                 const int grp = valid ? sh.grp[j] : 0;
                 const int marker = valid ? sh.marker[j] : -1;
@@ -678,10 +671,9 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
 
     // latency-bound loads of the draw phase, issued by EVERY workgroup before the
     // streaming loop (any of them may turn out to be the last arriver)
-    const MarkerMeta meta = p.sums_out ? MarkerMeta{-1, 0, false, false, 0.0, 0.0, 0.0} : load_marker_meta(p, d, nb, tid);
+    if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
     if (!p.sums_out) stage_rng(p, sh, tid);
     if (pend && tid < 3 * SEG) sh.pvl[tid] = p.desc->pv[tid / 3][tid % 3];
-    const PivotScan scan = p.sums_out ? PivotScan{0u, 0u} : load_pivot_scan(p, d, tid);
     if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
@@ -963,7 +955,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         }
         return;
     }
-    sweep_draw_phase<SEG>(p, d, nbs, sh, meta, scan);
+    sweep_draw_phase<SEG>(p, d, nbs, sh);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
@@ -983,13 +975,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     }
     const uint32_t nb2 = nbs[SEG - 1];
     if ((nb2 == 0 && !pend) || d.error) return;
-    const MarkerMeta meta = load_marker_meta(p, d, nb2, threadIdx.x);
-    const PivotScan scan = load_pivot_scan(p, d, threadIdx.x);
+    stage_marker_meta(p, d, nb2, threadIdx.x, sh);
     stage_rng(p, sh, threadIdx.x);
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
     if (threadIdx.x == 0) sh.tot[NR * sh.bcap] = p.sums_out[NR * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase<SEG>(p, d, nbs, sh, meta, scan);
+    sweep_draw_phase<SEG>(p, d, nbs, sh);
 }
 
 } // namespace hg
