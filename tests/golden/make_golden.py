@@ -167,6 +167,48 @@ def from_oracle():
                     tag + "_pi": np.array(pis), tag + "_order": np.array(orders), tag + "_rng_x": rx,
                     tag + "_rng_idx": np.array([ridx]), tag + "_csv": np.array(csv), tag + "_eps": ch.arr("eps").copy()})
     np.savez(os.path.join(GOLD, "chain_small.npz"), **out)
+
+    # BayesW: ARS known answers (the same numbers oracle/_ref/libarms.so gives; tests/test_bayesw_oracle.py checks
+    # that live when the reference build is present) and one small chain
+    import ctypes
+    import math
+    libc = ctypes.CDLL(None)
+    orc._bind_bw(L)
+    DENS = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_void_p)
+    dp = ctypes.POINTER(ctypes.c_double)
+    fn = L.orc_ars_arms_c
+    fn.argtypes = [dp, ctypes.c_int, dp, dp, DENS, ctypes.c_void_p, dp, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int, dp, dp, ctypes.c_int,
+                   ctypes.POINTER(ctypes.c_int)]
+    fn.restype = ctypes.c_int
+    ars = {}
+    for name, dens, xinit, xl, xr in (("normal", lambda x: -0.5 * x * x, [-1.0, -0.2, 0.3, 1.1], -6.0, 6.0),
+                                      ("gamma", lambda x: 2.5 * math.log(x) - 3 * x, [0.2, 0.6, 1.0, 2.0], 1e-3, 20.0)):
+        libc.srand(7)
+        cb, xs_, ne_ = DENS(lambda x, _d, f=dens: f(x)), [], []
+        for _ in range(100):
+            xi = (ctypes.c_double * 4)(*xinit)
+            a, b, cv, xp = ctypes.c_double(xl), ctypes.c_double(xr), ctypes.c_double(1.0), ctypes.c_double(0.0)
+            xs, qc, xc, ne = (ctypes.c_double * 1)(), (ctypes.c_double * 10)(5., 30., 70., 95.), (ctypes.c_double * 10)(), ctypes.c_int(0)
+            assert fn(xi, 4, ctypes.byref(a), ctypes.byref(b), cb, None, ctypes.byref(cv), 100, 0, ctypes.byref(xp), xs, 1, qc, xc, 4,
+                      ctypes.byref(ne)) == 0
+            xs_.append(xs[0])
+            ne_.append(ne.value)
+        ars[name + "_x"], ars[name + "_neval"] = np.array(xs_), np.array(ne_)
+    M, N = 40, 90
+    geno = synth.make_genotypes(M, N, seed=21, missing_rate=0.03)
+    y, fail, _ = synth.make_survival(geno, seed=22, causal_frac=0.2)
+    bed = synth.pack_bed_columns(geno)
+    ch = orc.BwChain(L, bed, N, y, fail, mS=np.array([[0.0, 0.001, 0.01]]), seed=1222, quad=7)
+    betas, comps, hyp, csv = [], [], [], []
+    for it in range(8):
+        ch.iterate()
+        betas.append(ch.arr("beta").copy())
+        comps.append(ch.arr("components").copy())
+        hyp.append([ch.mu, ch.alpha, ch.arr("sigmaG")[0]])
+        csv.append(ch.csv_line(it))
+    ars.update(bw_bed=bed, bw_y=y, bw_fail=fail, bw_beta=np.array(betas), bw_comp=np.array(comps), bw_hyper=np.array(hyp), bw_csv=np.array(csv),
+               bw_eps=ch.arr("eps").copy())
+    np.savez(os.path.join(GOLD, "bayesw_small.npz"), **ars)
     print("oracle fixtures written")
 
 

@@ -240,3 +240,54 @@ def test_oracle_bayesw_restore_is_exact(oracle, with_cov):
         w = want[it - 4]
         assert np.array_equal(b.arr("beta"), w[0]) and np.array_equal(b.arr("components"), w[1]) and np.array_equal(b.arr("eps"), w[2])
         assert b.mu == w[3] and b.alpha == w[4] and b.csv_line(it) == w[5]
+
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_ars_known_answers(orc_arms):
+    """tests/golden/bayesw_small.npz holds 100 draws per density made on rand() after srand(7): the numbers the
+    reference's arms() gives (test_oracle_ars_is_the_reference_ars proves that whenever oracle/_ref is built)."""
+    gold = np.load(os.path.join(GOLD, "bayesw_small.npz"))
+    for case in ("normal", "gamma"):
+        dens, xinit, xl, xr = CASES[case]
+        got = run_arms(orc_arms, dens, xinit, xl, xr, 100, 7)
+        assert [g[1] for g in got] == list(gold[case + "_x"]) and [g[2] for g in got] == list(gold[case + "_neval"])
+        assert [g[1] for g in run_product(dens, xinit, xl, xr, 100, 7)] == list(gold[case + "_x"])
+
+
+def test_bayesw_chain_regression(oracle):
+    gold = np.load(os.path.join(GOLD, "bayesw_small.npz"))
+    ch = orc.BwChain(oracle, gold["bw_bed"], 90, gold["bw_y"], gold["bw_fail"], mS=np.array([[0.0, 0.001, 0.01]]), seed=1222, quad=7)
+    for it in range(8):
+        ch.iterate()
+        assert np.array_equal(ch.arr("components"), gold["bw_comp"][it]) and np.array_equal(ch.arr("beta"), gold["bw_beta"][it])
+        assert [ch.mu, ch.alpha, ch.arr("sigmaG")[0]] == list(gold["bw_hyper"][it]) and ch.csv_line(it) == str(gold["bw_csv"][it])
+    assert np.array_equal(ch.arr("eps"), gold["bw_eps"])
+
+
+def test_ars_matches_reference_on_random_densities(orc_arms, ref_arms):
+    """Property: over random parameters of the four densities BayesW samples (shapes of mu_dens, alpha_dens,
+    beta_dens, gamma_dens) the restated sampler and the reference's arms() agree bit for bit."""
+    rng = np.random.default_rng(2024)
+    for trial in range(120):
+        kind = trial % 3
+        if kind == 0:   # beta_dens: -a x d - exp(a x m/s)(v0 + v1 exp(-a x/s) + v2 exp(-2 a x/s)) - x^2/(2 C sG)
+            a, d, m, s_ = rng.uniform(1, 12), rng.normal(0, 30), rng.uniform(0.05, 1.5), rng.uniform(0.2, 0.9)
+            v0, v1, v2, cs = rng.uniform(50, 5000), rng.uniform(10, 3000), rng.uniform(0, 500), rng.choice([1e-4, 1e-3, 1e-2]) * rng.uniform(0.01, 0.5)
+            dens = lambda x: -a * x * d - math.exp(a * x * m / s_) * (v0 + v1 * math.exp(-a * x / s_) + v2 * math.exp(-2 * a * x / s_)) - x * x / (2 * cs)
+            b0, L_ = rng.normal(0, 0.01), 2 * math.sqrt(rng.uniform(0.01, 0.3) * cs / rng.uniform(0.01, 0.5))
+            xinit, xl, xr = [b0 - L_ / 10, b0, b0 + L_ / 20, b0 + L_ / 10], b0 - L_, b0 + L_
+        elif kind == 1:  # alpha_dens: (a0 + d - 1) log x + x (S - k0) - sum exp(eps x - g)
+            eps = rng.normal(0, 0.3, size=40)
+            dd, S = 30.0, float((eps * (rng.random(40) < 0.8)).sum())
+            dens = lambda x: (0.01 + dd - 1) * math.log(x) + x * (S - 0.01) - float(np.exp(eps * x - 0.577215664901532).sum())
+            a0 = rng.uniform(1, 8)
+            xinit, xl, xr = [a0 * 0.5, a0, a0 * 1.05, a0 * 1.1], 0.0, a0 * 1.3
+        else:            # mu_dens: -a x d - sum exp((eps - x) a - g) - x^2 / 200
+            eps, a = rng.normal(3, 0.3, size=40), rng.uniform(1, 8)
+            dens = lambda x: -a * x * 30.0 - float(np.exp((eps - x) * a - 0.577215664901532).sum()) - x * x / 200.0
+            mu = 3.0 + rng.normal(0, 0.05)
+            xinit, xl, xr = [0.95 * mu, mu, 1.005 * mu, 1.01 * mu], 0.8 * mu, 1.1 * mu
+        seed = int(rng.integers(1, 2 ** 31))
+        assert run_arms(ref_arms, dens, xinit, xl, xr, 5, seed) == run_arms(orc_arms, dens, xinit, xl, xr, 5, seed), (trial, kind)
