@@ -90,10 +90,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("HGIBBS_LIB", LIB_PATH)  # A/B runs of two builds of the same ABI
+    if not os.path.exists(path):
         raise HgError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                      "(there is no CPU fallback)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                      "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     u8p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     L.hgibbs_last_error.restype = C.c_char_p
