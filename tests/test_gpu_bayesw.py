@@ -153,6 +153,37 @@ def test_longer_chain_stays_on_the_oracle(oracle):
     _chain_vs_oracle(oracle, M=250, N=1000, iters=25, seed=77, tol=1e-4)
 
 
+def test_full_size_properties_bayesw():
+    """BayesW at bench size (N = 100 000, M = 100 000 generated in HBM) through size-independent properties:
+    counts add up, vi == exp(alpha * eps - EuMasc) after a sweep of fused update + refresh launches, and
+    eps + X beta == y - mu - (what the intercept draws moved) via the update operator round trip."""
+    import bench
+    N, M = 100000, 100000
+    dev = capi.Device(0)
+    dev.synth_bed(N, M, seed=42)
+    y, fail = bench.make_survival_on_device(dev, N, M)
+    ch = capi.BwChain(dev, y, fail, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), seed=1222, quad=9)
+    for _ in range(2):
+        ch.iterate()
+    st = ch.state()
+    beta, comp = ch.beta()
+    assert st["cass"].sum() == M and st["m0"].sum() == (comp != 0).sum() and np.all((beta != 0) == (comp != 0))
+    ops_vi = np.zeros(N)
+    vs = C.c_double()
+    capi.check(dev.L.hgibbs_w_get_vi(dev.h, ops_vi.ctypes.data_as(C.POINTER(C.c_double)), C.byref(vs)))
+    eps = dev.get_residual()
+    want = np.exp(st["alpha"] * eps - 0.577215664901532)
+    assert close(ops_vi, want, 1e-13) and close(vs.value, want.sum(), 1e-11)
+    # eps = y - mu - X beta with BayesW's own standardisation (sd, not its inverse): rebuild X beta column by column
+    mave, sd, _ = [np.zeros(M) for _ in range(3)]
+    capi.check(dev.L.hgibbs_w_marker_stats(dev.h, mave.ctypes.data_as(C.POINTER(C.c_double)), sd.ctypes.data_as(C.POINTER(C.c_double)), None))
+    xb = np.zeros(N)
+    for j in np.flatnonzero(beta):
+        col = synth.unpack_bed_columns(dev.get_bed(int(j), 1), N)[0].astype(np.float64)
+        xb += np.where(col == 3, 0.0, (col - mave[j]) / sd[j]) * beta[j]
+    assert np.max(np.abs(eps + xb - (y - st["mu"]))) < 1e-9
+
+
 def test_argument_errors():
     _, bed, y, fail = make_case(20, 100)
     dev = capi.Device(0)

@@ -415,6 +415,44 @@ def test_full_size_properties_c2():
     assert close(res[0][3]["sigmaE"], res[1][3]["sigmaE"])
 
 
+@pytest.mark.parametrize("cfg", ["c3", "c4"])
+def test_full_size_properties_c3_c4(cfg):
+    """BASELINE configs 3 (N=200 000, M=500 000, two groups) and 4 (N=500 000, M=1 000 000: 125 GB of packed
+    genotypes in HBM) at full size through the same size-independent properties: counts add up, the residual
+    identity eps + X beta == y - mu holds after the sweeps (round trip through the update operator), and the
+    plain path (gram = 0, another batch width) walks the same chain as the Gram-corrected default."""
+    N, M, G = (200000, 500000, 2) if cfg == "c3" else (500000, 1000000, 1)
+    groups = None if G == 1 else (np.arange(M) % 2).astype(np.int32)
+    mS = np.array([[0.0, 0.0001, 0.001, 0.01]]) if G == 1 else np.array([[0.0, 0.001, 0.01, 0.1]] * 2)
+    res = []
+    for batch, gram in ((256, 1), (200, 0)):
+        dev = capi.Device(0)
+        dev.set_option("batch", batch)
+        dev.set_option("gram", gram)
+        dev.synth_bed(N, M, seed=42)
+        rng = np.random.default_rng(1)
+        dev.set_residual(rng.normal(size=N))
+        for j, b in zip(rng.choice(M, 300, replace=False), rng.normal(0, 0.04, 300)):
+            dev.update_marker(int(j), -float(b))
+        y = dev.get_residual()
+        ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=1222)
+        ys = dev.get_residual()
+        for _ in range(2):
+            ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st, eps = ch.state(), dev.get_residual()
+        res.append((beta, comp, eps, st))
+        assert st["cass"].sum() == M and st["m0"].sum() == (comp != 0).sum()
+        assert np.all((beta != 0) == (comp != 0)) and np.all((acum >= 0) & (acum <= 1.0 + 1e-12))
+        if gram:
+            for j in np.flatnonzero(beta):
+                dev.update_marker(int(j), float(beta[j]))
+            assert np.max(np.abs(dev.get_residual() - (ys - st["mu"]))) < 1e-8
+        dev.close()
+    assert np.array_equal(res[0][1], res[1][1]) and close(res[0][0], res[1][0]) and close(res[0][2], res[1][2])
+    assert close(res[0][3]["sigmaE"], res[1][3]["sigmaE"]) and close(res[0][3]["sigmaG"], res[1][3]["sigmaG"])
+
+
 # ---------------------------------------------------------------------------
 # edge cases of the model and of the data shapes
 # ---------------------------------------------------------------------------
