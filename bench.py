@@ -303,6 +303,7 @@ def main():
     ap.add_argument("--M", type=int, default=0, help="override markers")
     ap.add_argument("--batch", type=int, default=0, help="speculative batch width (0 = library default)")
     ap.add_argument("--cpg", type=int, default=0, help="columns per workgroup column-group")
+    ap.add_argument("--graph", type=int, default=-1, help="replay the sweep's launches from a HIP graph (1) or launch them one by one (0)")
     ap.add_argument("--max-seg", type=int, default=0, help="segments (predicted events) one launch may chain through (0 = library default)")
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
@@ -356,6 +357,8 @@ def main():
         dev.set_option("cols_per_group", args.cpg)
     if args.max_seg:
         dev.set_option("max_seg", args.max_seg)
+    if args.graph >= 0:
+        dev.set_option("graph", args.graph)
 
     t_setup = time.perf_counter()
     dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)

@@ -126,6 +126,7 @@ struct hgibbs_ctx {
     uint32_t ext_limit = 256;
     uint32_t max_seg = 2; // segments (predicted events) one launch chains through; 3-4 select the wider kernel tier (measured slower on one GPU)
     bool gram = true; // Gram-corrected continuation past the first predicted event
+    bool use_graph = false; // replay the sweep's launches from a captured graph
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
     hgibbs_sweep_stats stats{};
@@ -1019,6 +1020,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "graph")) {
+        h->use_graph = value != 0;
     } else if (!std::strcmp(name, "max_seg")) {
         if (value < 1 || value > MAX_SEG) return fail("hgibbs_set_option: max_seg %lld outside [1,%d]", (long long)value, MAX_SEG);
         h->max_seg = (uint32_t)value;
@@ -1195,13 +1198,41 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.slices_max = S;
     const dim3 grid(S * ngroups);
     uint64_t total_launches = 0;
+    auto launch_one = [&]() {
+        if (tier == 4) {
+            if (cpg == 4) k_sweep_batch<4, 4><<<grid, BLOCK, lds, h->stream>>>(p);
+            else k_sweep_batch<8, 4><<<grid, BLOCK, lds, h->stream>>>(p);
+        } else {
+            switch (cpg) {
+            case 2: k_sweep_batch<2, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 4: k_sweep_batch<4, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 8: k_sweep_batch<8, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            default: k_sweep_batch<16, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            }
+        }
+    };
+    // launch-bound inner loop: the launches of one sweep are identical (all state travels through the
+    // descriptor), so GRAPH_N of them are captured once per sweep into a graph and replayed
+    constexpr int GRAPH_N = 64;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    if (h->use_graph && !split) {
+        HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < GRAPH_N; ++i) launch_one();
+        HIP_TRY(hipStreamEndCapture(h->stream, &graph));
+        HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     double avg_accept = std::max(1.0, (double)batch * 0.5);
     for (;;) {
         const SweepDesc& dh = *h->desc_host;
         const uint32_t remaining = M - std::min(M, dh.cursor);
         int n = h->chunk > 0 ? h->chunk : (int)std::min<double>(2048.0, std::max(8.0, 1.25 * remaining / avg_accept + 2));
-        for (int i = 0; i < n; ++i) {
+        if (gexec) {
+            n = (n + GRAPH_N - 1) / GRAPH_N * GRAPH_N;
+            for (int i = 0; i < n; i += GRAPH_N) HIP_TRY(hipGraphLaunch(gexec, h->stream));
+        }
+        for (int i = 0; i < n && !gexec; ++i) {
             if (tier == 4) {
                 if (cpg == 4) k_sweep_batch<4, 4><<<grid, BLOCK, lds, h->stream>>>(p);
                 else k_sweep_batch<8, 4><<<grid, BLOCK, lds, h->stream>>>(p);
@@ -1235,6 +1266,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
 
     h->eps_cur = h->desc_host->cur;
     h->batch_seq = h->desc_host->seq;

@@ -212,6 +212,24 @@ def test_gram_extension_matches_oracle_and_plain_path(oracle, batch):
         assert fewer, "the extension never saved a launch: it is not being exercised"
 
 
+def test_graph_replay_is_the_same_chain():
+    """The sweep's launches replayed from a captured HIP graph (option "graph") walk the very same chain."""
+    M, N = 900, 3000
+    bed, y = make_case(M, N, seed=23)
+    out = []
+    for graph in (0, 1):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("graph", graph)
+        ch = capi.Chain(dev, y, seed=3)
+        for _ in range(4):
+            ch.iterate()
+        beta, comp, _ = dev.get_beta()
+        out.append((beta, comp, dev.get_residual(), ch.state()["rng_x"], dev.sweep_stats()["launches"]))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][:4], out[1][:4]))
+    assert out[1][4] >= out[0][4]  # replay rounds the launch count up to whole graphs; the extra launches find nothing to do
+
+
 @pytest.mark.parametrize("max_seg,cpg", [(3, 8), (4, 8), (4, 4)])
 def test_chained_segments_match_the_oracle(oracle, max_seg, cpg):
     """Up to four segments per launch (the wider kernel tier: three Gram terms per column, four pending
