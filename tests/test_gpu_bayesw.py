@@ -384,3 +384,23 @@ def test_cli_bayesw_restart_from_dump_files(oracle, tmp_path):
         assert close([float(x) for x in csv[k].split(",")], [float(x) for x in ref.csv_line(it).split(",")])
         if it % 3 == 0:
             ref.reseed_ars(seed + it)
+
+
+def test_bayesw_recovers_the_simulated_model():
+    """Not a parity statement: 50 iterations on Weibull data simulated with mu = 3, alpha = 4, 2 % causal markers."""
+    M, N = 2000, 4000
+    geno = synth.make_genotypes(M, N, seed=111)
+    y, fail, beta_true = synth.make_survival(geno, seed=112, causal_frac=0.02, mu=3.0, alpha=4.0)
+    dev = capi.Device(0)
+    dev.load_bed(synth.pack_bed_columns(geno), N)
+    ch = capi.BwChain(dev, y, fail, mS=np.array([[0.0, 0.001, 0.01]]), seed=1222, quad=9)
+    post, mus, alphas = np.zeros(M), [], []
+    for it in range(50):
+        ch.iterate()
+        if it >= 25:
+            post += ch.beta()[0] / 25.0
+            st = ch.state()
+            mus.append(st["mu"])
+            alphas.append(st["alpha"])
+    assert np.corrcoef(post, beta_true)[0, 1] > 0.85
+    assert abs(np.mean(mus) - 3.0) < 0.1 and abs(np.mean(alphas) - 4.0) < 0.6

@@ -835,3 +835,25 @@ def test_cli_restart_refuses_bad_inputs(tmp_path):
         f.write(struct.pack("<I", 1))
     r = subprocess.run(base + ["--chain-length", "9", "--save", "2", "--restart"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "Mismatch between expected and read" in r.stderr
+
+
+def test_sampler_recovers_the_simulated_model():
+    """Not a parity statement: 60 iterations at the size of the shipped example (N = 5 000, M = 10 000, 1 % causal,
+    h2 = 0.5) -- the posterior mean of the effects lines up with the simulated ones and the variance components
+    land near the truth."""
+    N, M = 5000, 10000
+    geno = synth.make_genotypes(M, N, seed=101)
+    y, beta_true = synth.make_phenotype(geno, seed=102, h2=0.5, causal_frac=0.01)
+    dev = capi.Device(0)
+    dev.load_bed(synth.pack_bed_columns(geno), N)
+    ch = capi.Chain(dev, y, seed=1222)
+    post, h2 = np.zeros(M), []
+    for it in range(60):
+        ch.iterate()
+        if it >= 30:
+            post += dev.get_beta()[0] / 30.0
+            st = ch.state()
+            h2.append(st["sigmaG"].sum() / (st["sigmaG"].sum() + st["sigmaE"]))
+    scale = np.sqrt(((y - y.mean()) ** 2).sum() / (N - 1))  # the chain works on the standardised phenotype
+    assert np.corrcoef(post, beta_true / scale)[0, 1] > 0.85
+    assert 0.35 < np.mean(h2) < 0.65
