@@ -124,3 +124,33 @@ def test_regression_vectors(oracle):
     oracle.orc_rng_shuffle(g, orc.iptr(v), 40)
     assert sorted(v) == list(range(40))
     assert np.array_equal(v, gold["shuffle40_gcc11"])  # libstdc++ 11 algorithm (toolchain dependent, src/BayesRRm.cpp:1688)
+
+
+def test_gamma_restatement_has_the_call_structure_of_the_reference_elf():
+    """Structural pin of the Boost 1.67 gamma_distribution restatement (orc_rng.h: orc_rgamma; hg_rng.h: rgamma)
+    against the reference's prebuilt binary, READ AS DATA (disassembled, never executed): the instantiated
+    gamma_distribution<double>::operator()(mt19937&) calls exactly one tan, one log, one pow, five exp and has two
+    call sites of the exponential's generate_int_float_pair -- what the restated algorithm needs: alpha > 1: tan,
+    log, exp (Cauchy rejection); alpha < 1: exponential draw, exp(-y/alpha), exp(-x) or pow(x, alpha - 1);
+    alpha == 1: exponential draw; and one exp in the wedge test of each of the two inlined exponential Ziggurats.
+    Skipped where the reference checkout or binutils are absent (the GPU box)."""
+    import re
+    import shutil
+    import subprocess
+    elf = "/root/reference/src/hydra"
+    if not os.path.exists(elf) or not shutil.which("nm") or not shutil.which("objdump"):
+        pytest.skip("reference ELF or binutils not available")
+    syms = subprocess.check_output(["nm", "-n", elf]).decode().splitlines()
+    addr = None
+    for i, l in enumerate(syms):
+        if "gamma_distributionIdEclINS0_23mersenne_twister_engine" in l:
+            addr = int(l.split()[0], 16)
+            nxt = next(int(m.split()[0], 16) for m in syms[i + 1:] if m.split()[0] != l.split()[0] and len(m.split()) == 3)
+            break
+    assert addr is not None, "gamma_distribution<double>::operator() not found in the ELF's symbol table"
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--start-address=0x%x" % addr, "--stop-address=0x%x" % nxt, elf]).decode()
+    calls = re.findall(r"call\s+[0-9a-f]+ <([^>]+)>", dis)
+    census = {name: sum(1 for c in calls if c == name) for name in ("tan", "log", "pow", "exp")}
+    assert census == {"tan": 1, "log": 1, "pow": 1, "exp": 5}
+    assert sum(1 for c in calls if "generate_int_float_pair" in c) == 2
+    assert not [c for c in calls if c.split("@")[0] not in ("tan", "log", "pow", "exp") and "generate_int_float_pair" not in c]
