@@ -154,3 +154,13 @@ def test_gamma_restatement_has_the_call_structure_of_the_reference_elf():
     assert census == {"tan": 1, "log": 1, "pow": 1, "exp": 5}
     assert sum(1 for c in calls if "generate_int_float_pair" in c) == 2
     assert not [c for c in calls if c.split("@")[0] not in ("tan", "log", "pow", "exp") and "generate_int_float_pair" not in c]
+    # its scalar double constants: 1, 2^-32 (uniform_01 on a 32-bit engine), the exponential Ziggurat's tail shift
+    # table_x[1], pi (tan(pi * u)) and 2 (sqrt(2 alpha - 1))
+    blob = open(elf, "rb").read()
+    consts = sorted({struct.unpack("<d", blob[int(a, 16) - 0x400000:int(a, 16) - 0x400000 + 8])[0]
+                     for a in re.findall(r"sd\s+0x[0-9a-f]+\(%rip\),%xmm\d+\s+# ([0-9a-f]+)", dis)})
+    import orc as _orc
+    L = _orc.load()
+    n = C.c_int()
+    ex = np.ctypeslib.as_array(L.orc_zig_table(2, C.byref(n)), shape=(257,))
+    assert consts == sorted([1.0, 2.0 ** -32, float(ex[1]), 3.14159265358979323846, 2.0])
