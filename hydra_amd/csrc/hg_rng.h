@@ -247,7 +247,31 @@ inline void mt_to_boost_words(const uint32_t* x, uint32_t idx, uint32_t* out /* 
     for (uint32_t k = idx; k < (uint32_t)MT_N; ++k) out[k - idx] = w[k];
 }
 
-// URBG view for std::shuffle (src/BayesRRm.cpp:1692 passes dist.rng)
+// std::shuffle(first, last, dist.rng) (src/BayesRRm.cpp:1692, :2653; src/BayesW.cpp:1368, :1462) as the
+// reference binary runs it: libstdc++ 6.5 (the ELF's .comment and rpath name gcc-6.5.0), i.e. for
+// i = 1 .. n-1 one uniform_int_distribution<unsigned long>(0, i) draw and a swap, with the distribution's
+// classic down-scaling on a 32-bit engine: scaling = (2^32 - 1) / (i + 1), reject draws >= (i + 1) * scaling,
+// index = draw / scaling.  (The ELF's std::shuffle instantiation shows exactly this div / imul / div around
+// its inlined generator.)  Later libstdc++ releases draw two indices per engine call and use Lemire's
+// method, so std::shuffle itself would tie the chain to the host's toolchain.
+template <class T>
+inline void shuffle_libstdcxx6(T* first, size_t n, Mt& g)
+{
+    const uint64_t urngrange = 0xffffffffull;
+    for (size_t i = 1; i < n; ++i) {
+        const uint64_t uerange = (uint64_t)i + 1; // n <= 2^32 - 1 markers: always the down-scaling branch
+        const uint64_t scaling = urngrange / uerange, past = uerange * scaling;
+        uint64_t ret;
+        do ret = g.next();
+        while (ret >= past);
+        ret /= scaling;
+        const T t = first[i];
+        first[i] = first[ret];
+        first[ret] = t;
+    }
+}
+
+// URBG view of the generator (for callers that want std:: algorithms on it)
 struct MtUrbg {
     typedef uint32_t result_type;
     Mt* g;

@@ -190,8 +190,7 @@ int hydra_chain_iterate(hydra_chain_t c)
 
     // :1691-1694
     if (c->shuffle) {
-        hg::MtUrbg u{&gen};
-        std::shuffle(c->order.begin(), c->order.end(), u);
+        hg::shuffle_libstdcxx6(c->order.data(), c->order.size(), gen);
     }
     std::fill(c->m0.begin(), c->m0.end(), 0);
 
@@ -226,8 +225,7 @@ int hydra_chain_iterate(hydra_chain_t c)
 
     // :2646-2681 fixed effects: one conditional normal per covariate, shuffled order
     if (c->C > 0) {
-        hg::MtUrbg u{&gen};
-        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        hg::shuffle_libstdcxx6(c->xI.data(), c->xI.size(), gen);
         const double sigmaF = 1.0; // s02F, src/BayesRRm.h:34 (sigmaF = s02F, :2680)
         const double sigE_sigF = c->sigmaE / sigmaF;
         const double dNm1 = (double)(c->N - 1);

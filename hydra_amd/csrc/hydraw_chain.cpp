@@ -242,8 +242,7 @@ int hydraw_chain_iterate(hydraw_chain_t c)
     }
     // 1a. fixed effects, :1365-1415
     if (c->C > 0) {
-        MtUrbg u{&gen};
-        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        hg::shuffle_libstdcxx6(c->xI.data(), c->xI.size(), gen);
         for (int i = 0; i < c->C; ++i) {
             const int col = (int)c->xI[i];
             const double gamma_old = c->gamma[col];
@@ -270,8 +269,7 @@ int hydraw_chain_iterate(hydraw_chain_t c)
     if (hgibbs_w_refresh_vi(c->dev, c->alpha)) return 1; // :1457-1459
 
     if (c->shuffle) { // :1461-1463
-        MtUrbg u{&gen};
-        std::shuffle(c->order.begin(), c->order.end(), u);
+        hg::shuffle_libstdcxx6(c->order.data(), c->order.size(), gen);
     }
     std::fill(c->m0.begin(), c->m0.end(), 0);
     c->rng.idx = gen.idx;

@@ -362,8 +362,7 @@ int orc_bw_iterate(orc_bw* c)
     }
     /* 1a. fixed effects, :1365-1415 */
     if (c->C > 0) {
-        MtUrbgW u{&c->rng};
-        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        orc_shuffle_u32(&c->rng, c->xI.data(), c->xI.size());
         for (int fix_i = 0; fix_i < c->C; ++fix_i) {
             const unsigned col = c->xI[fix_i];
             const double gamma_old = c->gamma[col];
@@ -400,8 +399,7 @@ int orc_bw_iterate(orc_bw* c)
     for (uint32_t i = 0; i < N; ++i) vi[i] = std::exp(c->alpha * eps[i] - BW_EULER); /* :1457-1459 */
 
     if (c->shuffle) { /* :1461-1463 */
-        MtUrbgW u{&c->rng};
-        std::shuffle(c->order.begin(), c->order.end(), u);
+        orc_shuffle_u32(&c->rng, reinterpret_cast<uint32_t*>(c->order.data()), c->order.size());
     }
     std::fill(c->m0.begin(), c->m0.end(), 0);
     std::fill(c->cass.begin(), c->cass.end(), 0);

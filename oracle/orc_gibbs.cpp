@@ -23,9 +23,9 @@
  * increasing individual index with one accumulator each (S1, S2, SM, Sall),
  * exactly what the reference's loops do with OpenMP disabled.
  *
- * std::shuffle is toolchain dependent (src/BayesRRm.cpp:1688-1692 says so); we
- * call the local libstdc++ one on a URBG view of the shared MT19937 state, as
- * the product's host driver does.
+ * std::shuffle is toolchain dependent (src/BayesRRm.cpp:1688-1692 says so); the
+ * reference binary was built against libstdc++ 6.5, whose algorithm is restated
+ * (orc_rng.h: orc_shuffle_u32), as the product's host driver does.
  */
 #include <algorithm>
 #include <cmath>
@@ -553,8 +553,7 @@ void orc_chain_iter_begin(orc_chain* c)
     c->mu = orc_norm_rng(&c->rng, epssum / dN, c->sigmaE / dN);
     for (uint32_t i = 0; i < N; ++i) c->eps[i] -= c->mu;
     if (c->shuffle) {
-        MtUrbg u{&c->rng};
-        std::shuffle(c->order.begin(), c->order.end(), u);
+        orc_shuffle_u32(&c->rng, reinterpret_cast<uint32_t*>(c->order.data()), c->order.size());
     }
     std::fill(c->m0.begin(), c->m0.end(), 0);
     std::fill(c->cass.begin(), c->cass.end(), 0);
@@ -598,8 +597,7 @@ void orc_chain_iter_end(orc_chain* c)
     }
 
     if (c->C > 0) { /* :2646-2681 */
-        MtUrbg u{&c->rng};
-        std::shuffle(c->xI.begin(), c->xI.end(), u);
+        orc_shuffle_u32(&c->rng, c->xI.data(), c->xI.size());
         const double sigmaF = 1.0;
         const double sigE_sigF = c->sigmaE / sigmaF;
         const double dNm1 = (double)(N - 1);
@@ -720,8 +718,7 @@ double orc_rng_inv_scaled_chisq(orc_mt* g, double dof, double scale) { return or
 void orc_rng_dirichlet(orc_mt* g, const double* alpha, int len, double* out) { orc_dirichlet_rng(g, alpha, len, out); }
 void orc_rng_shuffle(orc_mt* g, int* v, int n)
 {
-    MtUrbg u{g};
-    std::shuffle(v, v + n, u);
+    orc_shuffle_u32(g, reinterpret_cast<uint32_t*>(v), (size_t)n);
 }
 const double* orc_zig_table(int which, int* len)
 {

@@ -215,6 +215,31 @@ static inline double orc_norm_rng(orc_mt* g, double mean, double sigma2)
     return orc_unit_normal(g) * sigma + mean;
 }
 
+/* std::shuffle(first, last, dist.rng) as the reference binary runs it (src/BayesRRm.cpp:1692, :2653;
+ * src/BayesW.cpp:1368, :1462): libstdc++ 6.5's loop -- for i = 1..n-1 swap(v[i], v[d(0, i)]) -- with
+ * uniform_int_distribution<unsigned long>'s classic down-scaling on a 32-bit engine.  PINNED structurally:
+ * the ELF's std::shuffle<vector<int>::iterator, mt19937&> has this div / imul / div around its inlined
+ * generator and the toolchain strings say gcc-6.5.0.  (src/BayesRRm.cpp:1688-1692 warns that the result
+ * depends on the toolchain; the restatement removes that dependence.) */
+static inline void orc_shuffle_u32(orc_mt* g, uint32_t* v, size_t n)
+{
+    const uint64_t urngrange = 0xffffffffull;
+    for (size_t i = 1; i < n; ++i) {
+        const uint64_t uerange = (uint64_t)i + 1;
+        const uint64_t scaling = urngrange / uerange, past = uerange * scaling;
+        uint64_t ret;
+        do {
+            ret = orc_mt_next(g);
+        } while (ret >= past);
+        ret /= scaling;
+        {
+            const uint32_t t = v[i];
+            v[i] = v[ret];
+            v[ret] = t;
+        }
+    }
+}
+
 /* Distributions_boost::unif_rng() */
 static inline double orc_unif_rng(orc_mt* g) { return orc_unif01(g); }
 

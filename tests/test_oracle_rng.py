@@ -123,7 +123,7 @@ def test_regression_vectors(oracle):
     v = np.arange(40, dtype=np.int32)
     oracle.orc_rng_shuffle(g, orc.iptr(v), 40)
     assert sorted(v) == list(range(40))
-    assert np.array_equal(v, gold["shuffle40_gcc11"])  # libstdc++ 11 algorithm (toolchain dependent, src/BayesRRm.cpp:1688)
+    assert np.array_equal(v, gold["shuffle40"])  # libstdc++ 6.5 algorithm, restated (the reference binary's toolchain)
 
 
 def test_gamma_restatement_has_the_call_structure_of_the_reference_elf():
@@ -164,3 +164,52 @@ def test_gamma_restatement_has_the_call_structure_of_the_reference_elf():
     n = C.c_int()
     ex = np.ctypeslib.as_array(L.orc_zig_table(2, C.byref(n)), shape=(257,))
     assert consts == sorted([1.0, 2.0 ** -32, float(ex[1]), 3.14159265358979323846, 2.0])
+
+
+def test_shuffle_is_the_libstdcxx6_algorithm(oracle):
+    """The marker order of a given seed must not depend on the host's libstdc++: oracle and product (the GPU parity
+    tests compare their marker orders) restate the algorithm of the reference binary's toolchain, gcc 6.5 -- one
+    uniform_int_distribution(0, i) draw per element with the classic down-scaling.  Checked against an
+    independent Python statement of that algorithm on the MT19937 stream."""
+    g = orc.OrcMt()
+    oracle.orc_rng_seed(C.byref(g), 4321)
+    v = np.arange(1000, dtype=np.int32)
+    oracle.orc_rng_shuffle(C.byref(g), orc.iptr(v), 1000)
+    g2 = orc.OrcMt()
+    oracle.orc_rng_seed(C.byref(g2), 4321)
+    w = list(range(1000))
+    for i in range(1, 1000):
+        scaling = 0xffffffff // (i + 1)
+        past = (i + 1) * scaling
+        while True:
+            r = oracle.orc_rng_u32(C.byref(g2))
+            if r < past:
+                break
+        j = r // scaling
+        w[i], w[j] = w[j], w[i]
+    assert list(v) == w and sorted(w) == list(range(1000))
+    assert oracle.orc_rng_u32(C.byref(g)) == oracle.orc_rng_u32(C.byref(g2))  # same number of engine calls
+
+
+def test_reference_elf_shuffle_is_the_one_draw_per_element_form():
+    """Structural pin (ELF read as data): std::shuffle<vector<int>::iterator, mt19937&> in the reference binary
+    divides twice and multiplies once around its inlined generator (scaling = range / n, past = n * scaling,
+    index = draw / scaling) and the toolchain strings name gcc 6.5.0 -- the libstdc++ that predates the
+    two-indices-per-draw shuffle (gcc 7) and the Lemire-style uniform_int_distribution (gcc 11)."""
+    import re
+    import shutil
+    import subprocess
+    elf = "/root/reference/src/hydra"
+    if not os.path.exists(elf) or not shutil.which("nm") or not shutil.which("objdump") or not shutil.which("readelf"):
+        pytest.skip("reference ELF or binutils not available")
+    assert "GCC: (GNU) 6.5.0" in subprocess.check_output(["readelf", "-p", ".comment", elf]).decode()
+    syms = subprocess.check_output(["nm", "-n", elf]).decode().splitlines()
+    idx = next(i for i, l in enumerate(syms) if "_ZSt7shuffleIN9__gnu_cxx17__normal_iteratorIPiSt6vectorIiSaIiEEEE" in l)
+    addr = int(syms[idx].split()[0], 16)
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--start-address=0x%x" % addr, "--stop-address=0x%x" % (addr + 0x5a0), elf]).decode()
+    ops = [l.split("\t")[-1].split()[0] for l in dis.splitlines() if "\t" in l]
+    first_call = next(i for i, l in enumerate(dis.splitlines()) if "uniform_int_distribution" in l)
+    head = [l.split("\t")[-1] for l in dis.splitlines()[:first_call] if "\t" in l]
+    divs = [h for h in head if h.startswith("div")]
+    assert len(divs) == 2 and any(h.startswith("imul") and "$0x" not in h for h in head)
+    assert ops.count("div") == 2
