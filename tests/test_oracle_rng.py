@@ -213,3 +213,21 @@ def test_reference_elf_shuffle_is_the_one_draw_per_element_form():
     divs = [h for h in head if h.startswith("div")]
     assert len(divs) == 2 and any(h.startswith("imul") and "$0x" not in h for h in head)
     assert ops.count("div") == 2
+
+
+def test_reference_elf_beta_is_two_gammas_and_a_ratio():
+    """Structural pin (ELF read as data) of beta_rng = x / (x + y), x ~ gamma(a, 1), y ~ gamma(b, 1)
+    (orc_beta_rng; used once at start-up for sigmaG, src/BayesRRm.cpp:1233): two calls of the gamma sampler,
+    three divisions (one e / (alpha + e) per gamma parameter set, then the ratio)."""
+    import re
+    import shutil
+    import subprocess
+    elf = "/root/reference/src/hydra"
+    if not os.path.exists(elf) or not shutil.which("nm") or not shutil.which("objdump"):
+        pytest.skip("reference ELF or binutils not available")
+    syms = subprocess.check_output(["nm", "-n", elf]).decode().splitlines()
+    addr = next(int(l.split()[0], 16) for l in syms if l.endswith("_ZN19Distributions_boost8beta_rngEdd"))
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--start-address=0x%x" % addr, "--stop-address=0x%x" % (addr + 0xe0), elf]).decode()
+    body = dis[:dis.index("ret")]
+    assert len(re.findall(r"call\s+[0-9a-f]+ <_ZN5boost6random18gamma_distributionIdEclI", body)) == 2
+    assert len(re.findall(r"\bvdivsd\b", body)) == 3
