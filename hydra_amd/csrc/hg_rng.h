@@ -271,13 +271,4 @@ inline void shuffle_libstdcxx6(T* first, size_t n, Mt& g)
     }
 }
 
-// URBG view of the generator (for callers that want std:: algorithms on it)
-struct MtUrbg {
-    typedef uint32_t result_type;
-    Mt* g;
-    static constexpr result_type min() { return 0u; }
-    static constexpr result_type max() { return 0xffffffffu; }
-    result_type operator()() { return g->next(); }
-};
-
 } // namespace hg

@@ -43,14 +43,6 @@ const double BW_EULER = 0.577215664901532;
 /* src/BayesW.hpp:85-89 */
 const double BW_ALPHA_0 = 0.01, BW_KAPPA_0 = 0.01, BW_SIGMA_MU = 100, BW_ALPHA_SIGMA = 1, BW_BETA_SIGMA = 0.0001;
 
-struct MtUrbgW {
-    typedef uint32_t result_type;
-    orc_mt* g;
-    static constexpr result_type min() { return 0u; }
-    static constexpr result_type max() { return 0xffffffffu; }
-    result_type operator()() { return orc_mt_next(g); }
-};
-
 inline int geno_at(const uint8_t* col, uint32_t i)
 {
     const unsigned v = (col[i >> 2] >> (2 * (i & 3u))) & 3u; /* src/data.cpp:1189-1200 */

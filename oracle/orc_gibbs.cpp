@@ -47,16 +47,6 @@
 
 namespace {
 
-/* URBG view over the shared generator: what `dist.rng` (boost::mt19937) is to
- * std::shuffle at src/BayesRRm.cpp:1692. */
-struct MtUrbg {
-    typedef uint32_t result_type;
-    orc_mt* g;
-    static constexpr result_type min() { return 0u; }
-    static constexpr result_type max() { return 0xffffffffu; }
-    result_type operator()() { return orc_mt_next(g); }
-};
-
 /* a1: src/data.cpp:1189-1200 -- code v=(byte>>2i)&3; v==1 missing, else 2-(b0+b1) */
 inline int decode_code(unsigned v)
 {
