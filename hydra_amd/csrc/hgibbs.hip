@@ -119,12 +119,13 @@ struct hgibbs_ctx {
     double* beta_host = nullptr;    // pinned, M doubles (lazy)
 
     // options
-    uint32_t batch = 0; // 0 = auto: 256 for shards of >= 200k individuals or several ranks, else 128
+    uint32_t batch = 0; // 0 = auto: 256 for shards of >= 20k individuals or several ranks, else 128
     uint32_t cols_per_group = 8;
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
     uint32_t ext_limit = 256;
-    uint32_t max_seg = 2; // segments (predicted events) one launch chains through; 3-4 select the wider kernel tier (measured slower on one GPU)
+    uint32_t max_seg = 0; // segments (predicted events) one launch chains through; 0 = auto: 4 (the wider kernel tier) for shards of up to
+                          // 100k individuals, where a launch is dominated by its fixed cost, else 2 (config 4: 2.84 vs 2.31 M markers/s)
     bool gram = true; // Gram-corrected continuation past the first predicted event
     bool use_graph = false; // replay the sweep's launches from a captured graph
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
@@ -1023,7 +1024,7 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "graph")) {
         h->use_graph = value != 0;
     } else if (!std::strcmp(name, "max_seg")) {
-        if (value < 1 || value > MAX_SEG) return fail("hgibbs_set_option: max_seg %lld outside [1,%d]", (long long)value, MAX_SEG);
+        if (value < 0 || value > MAX_SEG) return fail("hgibbs_set_option: max_seg %lld outside [0,%d]", (long long)value, MAX_SEG);
         h->max_seg = (uint32_t)value;
     } else if (!std::strcmp(name, "ext_limit")) {
         if (value < 0 || value > MAX_BATCH) return fail("ext_limit must be in [0,%d]", MAX_BATCH);
@@ -1109,7 +1110,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipGetLastError());
 
     const uint32_t cpg = h->cols_per_group;
-    const uint32_t batch = h->batch ? h->batch : ((h->n_local >= 200000u || h->nranks > 1) ? 256u : 128u);
+    const uint32_t batch = h->batch ? h->batch : ((h->n_local >= 20000u || h->nranks > 1) ? 256u : 128u);
     const uint32_t ngroups = (batch + cpg - 1) / cpg;
     SweepDesc d0{};
     d0.cursor = 0;
@@ -1167,7 +1168,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
     p.ext_limit = h->ext_limit;
-    p.max_seg = std::max<uint32_t>(1u, std::min<uint32_t>(h->max_seg, MAX_SEG));
+    p.max_seg = h->max_seg ? std::min<uint32_t>(h->max_seg, MAX_SEG) : ((h->n_local <= (h->nranks > 1 ? 150000u : 100000u)) ? 4u : 2u);
     // two builds of the kernel: tier 2 (one Gram term, two pending updates: lean registers, 3 workgroups per CU) and
     // tier 4 (three Gram terms, four pending updates; cols_per_group 4 or 8 only)
     const int tier = (p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
