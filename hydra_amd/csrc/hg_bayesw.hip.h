@@ -62,6 +62,7 @@ struct BwBatchParams {
     int quad;
     const double* vipart; // block partials of sum(vi) from the last refresh
     uint32_t n_vipart;
+    double* rows;         // several ranks: BW_ROWS local row sums (k_bw_rows), all-reduced before the tail reads them; else null
     BwResult* result;     // pinned host memory
     unsigned long long seq;
     int32_t* picks;       // MAX_BATCH + 1
@@ -322,6 +323,38 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
     }
 }
 
+// Individuals sharded over several GPUs: this rank's row sums (slice partials per column, the shifted
+// column's three, the partials of sum(vi)) in one dense buffer for the all-reduce between k_bw_sums and k_bw_tail.
+// rows[2c], rows[2c+1]; rows[2*MAX_BATCH .. +2] the shifted column; rows[2*MAX_BATCH+3] = sum(vi).
+__global__ __launch_bounds__(WAVE) void k_bw_rows(BwBatchParams p)
+{
+    const int lane = threadIdx.x;
+    const uint32_t col = blockIdx.x;
+    const uint32_t nb = p.ncols + (p.shifted_marker >= 0 ? 1u : 0u);
+    if (col == nb) {
+        double v = 0.0;
+        for (uint32_t b = lane; b < p.n_vipart; b += WAVE) v += p.vipart[b];
+        v = wave_sum(v);
+        if (lane == 0) p.rows[2 * MAX_BATCH + 3] = v;
+        return;
+    }
+    const bool shifted = col >= p.ncols;
+    const uint32_t r0 = shifted ? 2 * MAX_BATCH : 2 * col;
+    const double* row = p.partials + (size_t)lane * BW_ROWS + r0;
+    const bool live = (uint32_t)lane < p.slices;
+    double t0 = live ? __hip_atomic_load(row, HG_RLX_AGENT) : 0.0;
+    double t1 = live ? __hip_atomic_load(row + 1, HG_RLX_AGENT) : 0.0;
+    double t2 = (live && shifted) ? __hip_atomic_load(row + 2, HG_RLX_AGENT) : 0.0;
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if (lane == 0) {
+        p.rows[r0] = t0;
+        p.rows[r0 + 1] = t1;
+        if (shifted) p.rows[r0 + 2] = t2;
+    }
+}
+
 // One wavefront per column: reduce the column's slice partials, evaluate every (component, node)
 // term of the quadrature on its own lane, sum them in the reference's order, walk the components
 // with the column's uniform.  The last wavefront to finish reports the first event of the batch
@@ -339,21 +372,26 @@ __global__ __launch_bounds__(WAVE) void k_bw_tail(BwBatchParams p)
 
     // fixed-order (wave tree) sums over the S <= 64 slices; sum(vi) from the refresh kernel's block partials
     const uint32_t r0 = shifted ? 2 * MAX_BATCH : 2 * col;
-    const double* row = p.partials + (size_t)lane * BW_ROWS + r0;
-    const bool live = (uint32_t)lane < S;
-    double t0 = live ? __hip_atomic_load(row, HG_RLX_AGENT) : 0.0;
-    double t1 = live ? __hip_atomic_load(row + 1, HG_RLX_AGENT) : 0.0;
-    double t2 = (live && shifted) ? __hip_atomic_load(row + 2, HG_RLX_AGENT) : 0.0;
-    t0 = wave_sum(t0);
-    t1 = wave_sum(t1);
     bw::MarkerSums sums;
-    if (shifted) {
-        t2 = wave_sum(t2);
-        sums = bw::MarkerSums{t0, t1, t2};
+    if (p.rows) { // summed over the ranks already
+        if (shifted) sums = bw::MarkerSums{p.rows[r0], p.rows[r0 + 1], p.rows[r0 + 2]};
+        else sums = bw::MarkerSums{p.rows[2 * MAX_BATCH + 3], p.rows[r0], p.rows[r0 + 1]};
     } else {
-        double v = 0.0;
-        for (uint32_t b = lane; b < p.n_vipart; b += WAVE) v += p.vipart[b];
-        sums = bw::MarkerSums{wave_sum(v), t0, t1};
+        const double* row = p.partials + (size_t)lane * BW_ROWS + r0;
+        const bool live = (uint32_t)lane < S;
+        double t0 = live ? __hip_atomic_load(row, HG_RLX_AGENT) : 0.0;
+        double t1 = live ? __hip_atomic_load(row + 1, HG_RLX_AGENT) : 0.0;
+        double t2 = (live && shifted) ? __hip_atomic_load(row + 2, HG_RLX_AGENT) : 0.0;
+        t0 = wave_sum(t0);
+        t1 = wave_sum(t1);
+        if (shifted) {
+            t2 = wave_sum(t2);
+            sums = bw::MarkerSums{t0, t1, t2};
+        } else {
+            double v = 0.0;
+            for (uint32_t b = lane; b < p.n_vipart; b += WAVE) v += p.vipart[b];
+            sums = bw::MarkerSums{wave_sum(v), t0, t1};
+        }
     }
     const int marker = shifted ? p.shifted_marker : p.markers[col];
     const int grp = p.groups[marker];
@@ -430,6 +468,7 @@ struct BwState {
     BwResult* h_result = nullptr; // pinned, written by the device
     unsigned long long seq = 0;
     double* vipart = nullptr; // block partials of sum(vi) from the last refresh
+    double* d_rows = nullptr; // BW_ROWS: this rank's row sums, all-reduced between the two batch kernels (several ranks only)
     int32_t* d_colk = nullptr;
     uint32_t* d_first_event = nullptr;
     hipEvent_t evk0 = nullptr, evk1 = nullptr;
@@ -448,7 +487,7 @@ static void bw_free(BwState* b)
 {
     if (!b) return;
     void* ptrs[] = {b->vi, b->failspread, b->vi_sum, b->d_mave, b->d_sd, b->d_sumfail, b->d_cva, b->d_pi, b->d_sigmaG, b->d_ghx, b->d_ghw,
-                    b->d_unif, b->partials, b->d_picks, b->d_colsums, b->vipart, b->d_colk, b->d_first_event};
+                    b->d_unif, b->partials, b->d_picks, b->d_colsums, b->vipart, b->d_colk, b->d_first_event, b->d_rows};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_result) (void)hipHostFree(b->h_result);
@@ -461,7 +500,6 @@ static int bw_need(hgibbs_ctx* h, const char* who, bool tables = false, bool mod
 {
     if (!h || !h->bed) return fail("%s: load genotypes first", who);
     if (!h->bw) return fail("%s: call hgibbs_w_init first", who);
-    if (h->nranks > 1) return fail("%s: BayesW runs on one GPU in this build (individuals are not sharded for it)", who);
     if (tables && !h->bw->have_tables) return fail("%s: call hgibbs_w_marker_stats first", who);
     if (model && !h->bw->have_model) return fail("%s: call hgibbs_w_set_model first", who);
     return 0;
@@ -480,7 +518,6 @@ extern "C" {
 int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host)
 {
     if (!h || !h->bed || !failure_host) return fail("hgibbs_w_init: load genotypes first and pass the failure indicator");
-    if (h->nranks > 1) return fail("hgibbs_w_init: BayesW runs on one GPU in this build");
     HIP_TRY(hipSetDevice(h->device));
     if (h->bw) return fail("hgibbs_w_init: already initialised on this handle");
     for (uint32_t i = 0; i < h->n_global; ++i)
@@ -504,6 +541,8 @@ int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host)
     std::memset(b->h_result, 0, sizeof(BwResult));
     HIP_TRY(hipMalloc(&b->vipart, (size_t)(h->n_pad / BLOCK_IND) * sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_colk, (MAX_BATCH + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&b->d_rows, (size_t)BW_ROWS * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(b->d_rows, 0, (size_t)BW_ROWS * sizeof(double), h->stream));
     HIP_TRY(hipMalloc(&b->d_first_event, sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(b->d_first_event, 0xff, sizeof(uint32_t), h->stream));
     HIP_TRY(hipEventCreate(&b->evk0));
@@ -540,6 +579,7 @@ int hgibbs_w_marker_stats(hgibbs_t h, double* mave, double* sd, double* sum_fail
         HIP_TRY(hipMalloc(&d_fc, fc.size() * sizeof(unsigned long long)));
         k_bw_fail_counts<<<M, BLOCK, 0, h->stream>>>(h->bed, h->stride, b->failspread, h->n_pad / 16, d_fc);
         HIP_TRY(hipGetLastError());
+        if (bulk_allreduce(h, d_fc, fc.size(), 1)) return 1; // individuals are sharded: counts add over the ranks
         HIP_TRY(hipMemcpyAsync(fc.data(), d_fc, fc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipFree(d_fc));
@@ -622,6 +662,7 @@ int hgibbs_w_reduce(hgibbs_t h, int kind, int col, double p0, double p1, double 
     k_bw_reduce<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], kind == 2 ? h->covX + (size_t)col * h->n_pad : nullptr, h->bw->failspread,
                                                kind, p0, p1, p2, h->n_local, h->scratch);
     if (bw_final(h, nblk, h->sums)) return 1;
+    if (bulk_allreduce(h, h->sums, 1, 0)) return 1; // every rank gets the same bits: the ARS decisions stay replicated
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *out = h->scratch_host[0];
@@ -654,6 +695,7 @@ int hgibbs_w_get_vi(hgibbs_t h, double* vi_host, double* vi_sum)
     if (vi_sum) {
         k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->bw->vipart, h->n_pad / BLOCK_IND, 1, h->bw->vi_sum);
         HIP_TRY(hipGetLastError());
+        if (bulk_allreduce(h, h->bw->vi_sum, 1, 0)) return 1;
         HIP_TRY(hipMemcpyAsync(vi_sum, h->bw->vi_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
@@ -795,6 +837,7 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         p.quad = b->quad;
         p.vipart = b->vipart;
         p.n_vipart = nblk;
+        p.rows = (h->nranks > 1) ? b->d_rows : nullptr;
         p.result = b->h_result;
         p.seq = ++b->seq;
         p.picks = b->d_picks;
@@ -804,6 +847,11 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk0, h->stream));
         k_bw_sums<CPG><<<S * ngroups, BLOCK, 0, h->stream>>>(p);
         if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk1, h->stream));
+        if (p.rows) { // individuals sharded: the row sums add over the ranks, same bits everywhere
+            k_bw_rows<<<nb + 1, WAVE, 0, h->stream>>>(p);
+            HIP_TRY(hipGetLastError());
+            if (bulk_allreduce(h, b->d_rows, BW_ROWS, 0)) return 1;
+        }
         k_bw_tail<<<nb, WAVE, 0, h->stream>>>(p);
         HIP_TRY(hipGetLastError());
         ++launches;
@@ -916,6 +964,7 @@ int hgibbs_w_marker_sums(hgibbs_t h, uint32_t marker, double beta_old, double al
                                        h->n_local, part);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(part, nblk, 3, h->sums);
     HIP_TRY(hipGetLastError());
+    if (bulk_allreduce(h, h->sums, 3, 0)) return 1;
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (vi_sum) *vi_sum = h->scratch_host[0];

@@ -10,7 +10,7 @@
 // [--ignore-xfiles] resumes from those dumps into <name>_rs.* (:842-928,
 // :1197-1220).
 //
-// `--mpibayes bayesWMPI --failure F --quad_points Q` runs BayesW (src/BayesW.cpp:905) on one GPU.
+// `--mpibayes bayesWMPI --failure F --quad_points Q` runs BayesW (src/BayesW.cpp:905), sharded the same way.
 //
 // Not reproduced (out of scope for the hot path): sparse
 // file formats, bayesFH, marker-sharded MPI, the .lst/tarball.
@@ -390,6 +390,81 @@ void write_rng_file(const std::string& path, const hgibbs_rng_state& st)
     for (int i = 0; i < 624; ++i) out << w[i] << (i + 1 < 624 ? " " : "");
 }
 
+// Several ranks (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK in the environment): the RCCL id and the
+// IPC handles of the in-launch peer mailboxes travel through files next to the outputs.
+void setup_ranks(hgibbs_t dev, const std::string& base, int rank, int nranks)
+{
+        uint8_t id[128];
+        const std::string idf = base + ".ncclid";
+        if (rank == 0) {
+            hg_check(hgibbs_comm_unique_id(id), "hgibbs_comm_unique_id");
+            FILE* f = std::fopen((idf + ".tmp").c_str(), "wb");
+            if (!f || std::fwrite(id, 1, 128, f) != 128) fatal("FATAL  : can not write " + idf);
+            std::fclose(f);
+            std::rename((idf + ".tmp").c_str(), idf.c_str());
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = std::fopen(idf.c_str(), "rb")); ++tries)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || std::fread(id, 1, 128, f) != 128) fatal("FATAL  : can not read " + idf);
+            std::fclose(f);
+        }
+        hg_check(hgibbs_comm_init(dev, nranks, rank, id), "hgibbs_comm_init");
+        // in-launch peer-mailbox exchange: every rank publishes its IPC handle next to the id file
+        uint8_t mine[64];
+        std::vector<uint8_t> all((size_t)nranks * 64);
+        bool p2p_ok = hgibbs_p2p_export(dev, mine) == 0;
+        {
+            const std::string hf = base + ".p2p." + std::to_string(rank);
+            FILE* f = std::fopen((hf + ".tmp").c_str(), "wb");
+            if (f) {
+                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
+                std::fwrite(mine, 1, 64, f);
+                std::fclose(f);
+                std::rename((hf + ".tmp").c_str(), hf.c_str());
+            }
+        }
+        for (int r = 0; r < nranks; ++r) {
+            const std::string hf = base + ".p2p." + std::to_string(r);
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = std::fopen(hf.c_str(), "rb")); ++tries)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            char flag = 'N';
+            if (!f || std::fread(&flag, 1, 1, f) != 1 || std::fread(all.data() + (size_t)r * 64, 1, 64, f) != 64 || flag != 'Y') p2p_ok = false;
+            if (f) std::fclose(f);
+        }
+        if (p2p_ok && hgibbs_p2p_import(dev, all.data()) != 0) p2p_ok = false;
+        // a rank that could not import falls back to RCCL; all ranks must agree, so publish the verdict too
+        {
+            const std::string vf = base + ".p2pok." + std::to_string(rank);
+            FILE* f = std::fopen((vf + ".tmp").c_str(), "wb");
+            if (f) {
+                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
+                std::fclose(f);
+                std::rename((vf + ".tmp").c_str(), vf.c_str());
+            }
+            for (int r = 0; r < nranks; ++r) {
+                const std::string of = base + ".p2pok." + std::to_string(r);
+                FILE* g = nullptr;
+                for (int tries = 0; tries < 6000 && !(g = std::fopen(of.c_str(), "rb")); ++tries)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                char flag = 'N';
+                if (!g || std::fread(&flag, 1, 1, g) != 1 || flag != 'Y') p2p_ok = false;
+                if (g) std::fclose(g);
+            }
+        }
+        hg_check(hgibbs_set_option(dev, "p2p", p2p_ok ? 1 : 0), "p2p");
+        if (rank == 0) std::printf("INFO   : per-batch exchange over %s\n", p2p_ok ? "xGMI peer mailboxes (in-launch)" : "RCCL all-reduce");
+        if (rank == 0) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(500));
+            std::remove(idf.c_str());
+            for (int r = 0; r < nranks; ++r) {
+                std::remove((base + ".p2p." + std::to_string(r)).c_str());
+                std::remove((base + ".p2pok." + std::to_string(r)).c_str());
+            }
+        }
+}
+
 // Data::readPhenFailFiles / readPhenFailCovFiles, src/data.cpp:1681-1802: .phen, .fail (and .cov)
 // are read line by line in lockstep; an individual is dropped if its phenotype is NA, its failure
 // indicator is -9, or any covariate is NA.
@@ -434,11 +509,10 @@ void read_phen_fail(const std::string& phen, const std::string& failf, const std
     C = (y.empty() || cov.empty()) ? 0 : (int)(X.size() / y.size());
 }
 
-// --mpibayes bayesWMPI: BayesW::runMpiGibbs_bW, src/BayesW.cpp:905-2176 (one GPU)
+// --mpibayes bayesWMPI: BayesW::runMpiGibbs_bW, src/BayesW.cpp:905-2176
 int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
 {
     Options opt = opt_in;
-    if (nranks > 1) fatal("FATAL  : bayesWMPI runs on one GPU in this build");
     if (opt.failureFile.empty()) fatal("FATAL  : --failure is mandatory with --mpibayes bayesWMPI");
     if (opt.quad_points.empty()) fatal("Possible number of quad_points = 3,5,7,9,11,13,15,17,25"); // src/BayesW.cpp:706-708
     const int quad = std::atoi(opt.quad_points.c_str());
@@ -492,9 +566,13 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
 
     hgibbs_t dev = nullptr;
     hg_check(hgibbs_create(local_rank, &dev), "hgibbs_create");
+    if (nranks > 1) setup_ranks(dev, base, rank, nranks);
     if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
     const double tl0 = now_s();
     const size_t snpLenByt = (numInds + 3) / 4;
+    // individuals sharded in multiples of 4 of the KEPT rows
+    const unsigned per = ((Ntot + nranks - 1) / nranks + 3) / 4 * 4;
+    const unsigned lo = std::min(Ntot, rank * per), hi = std::min(Ntot, (rank + 1) * per);
     {
         std::vector<uint8_t> bed;
         std::ifstream in(opt.bedFile + ".bed", std::ios::binary);
@@ -505,7 +583,7 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
         bed.resize((size_t)Mtot * snpLenByt);
         in.read((char*)bed.data(), (std::streamsize)bed.size());
         if ((size_t)in.gcount() != bed.size()) fatal("FATAL  : " + opt.bedFile + ".bed is shorter than M x ceil(N/4)");
-        hg_check(hgibbs_load_bed(dev, bed.data(), snpLenByt, (uint32_t)numInds, Mtot, numNAs ? keep.data() : nullptr, 0, Ntot, Ntot), "hgibbs_load_bed");
+        hg_check(hgibbs_load_bed(dev, bed.data(), snpLenByt, (uint32_t)numInds, Mtot, numNAs ? keep.data() : nullptr, lo, hi, Ntot), "hgibbs_load_bed");
         std::printf("INFO   : rank %3d took %.3f seconds to load  %lu bytes  =>  BW = %7.3f GB/s\n", rank, now_s() - tl0, (unsigned long)bed.size(),
                     (double)bed.size() * 1e-9 / (now_s() - tl0));
     }
@@ -564,7 +642,9 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
         read_marker_history(base_in + (xf ? ".xcpn" : ".cpn"), xf, Mtot, it_from, first_thinned, opt.thin, sizeof(int32_t), r_comp.data());
         unsigned len = 0;
         std::vector<uint8_t> eb = read_dump(base_in + ".eps." + std::to_string(rank), it_from, sizeof(double), &len);
-        expect_u(len, Ntot, ".eps Ntot");
+        const double* r_eps = (const double*)eb.data();
+        if (len == Ntot && len != hi - lo) r_eps += lo; // a full-length dump is sliced
+        else expect_u(len, hi - lo, ".eps Ntot");
         std::vector<uint8_t> mb = read_dump(base_in + ".mrk." + std::to_string(rank), it_from, sizeof(int32_t), &len);
         expect_u(len, Mtot, ".mrk M");
         std::vector<double> r_gamma(C);
@@ -595,7 +675,7 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
         rs.pi = r_pi.data();
         rs.beta = r_beta.data();
         rs.components = r_comp.data();
-        rs.eps = (const double*)eb.data();
+        rs.eps = r_eps;
         rs.order = (const int32_t*)mb.data();
         rs.gamma = opt.covariates ? r_gamma.data() : nullptr;
         rs.xI = opt.covariates ? (const int32_t*)xb.data() : nullptr;
@@ -613,18 +693,20 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
         if (!f) fatal("FATAL  : can not create " + p);
         return f;
     };
-    FILE* outf = open_trunc(base + ".csv");
-    FILE* betf = open_trunc(base + ".bet");
-    FILE* cpnf = open_trunc(base + ".cpn");
-    FILE* xbetf = open_trunc(base + ".xbet");
-    FILE* xcpnf = open_trunc(base + ".xcpn");
-    FILE* gamf = open_trunc(base + ".gam"); // text, one line per thinned iteration (:1966-1977)
-    FILE* xivf = open_trunc(base + ".xiv");
+    // the shared files are rank 0's (every rank holds the same chain); the others write theirs into the void
+    auto open_shared = [&](const std::string& p) { return open_trunc(rank == 0 ? p : std::string("/dev/null")); };
+    FILE* outf = open_shared(base + ".csv");
+    FILE* betf = open_shared(base + ".bet");
+    FILE* cpnf = open_shared(base + ".cpn");
+    FILE* xbetf = open_shared(base + ".xbet");
+    FILE* xcpnf = open_shared(base + ".xcpn");
+    FILE* gamf = open_shared(base + ".gam"); // text, one line per thinned iteration (:1966-1977)
+    FILE* xivf = open_shared(base + ".xiv");
     FILE* epsf = open_trunc(base + ".eps." + std::to_string(rank));
     FILE* mrkf = open_trunc(base + ".mrk." + std::to_string(rank));
     for (FILE* f : {betf, xbetf, cpnf, xcpnf}) pwrite_at(f, 0, &Mtot, sizeof(unsigned)); // :1096-1101
 
-    std::vector<double> beta(Mtot), eps(Ntot), sigmaG(G), gamma(C);
+    std::vector<double> beta(Mtot), eps(hi - lo), sigmaG(G), gamma(C);
     std::vector<int32_t> comp(Mtot), m0(G), xiv(C);
     std::vector<char> buff(50000);
     unsigned n_thinned_saved = 0;
@@ -641,8 +723,8 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
             sg += sigmaG[g];
             m0s += m0[g];
         }
-        std::printf("%u. %ld; %.7g; %.7g; %.7g\n", iteration, m0s, mu, alpha, sg); // :1906-1908
-        std::printf("RESULT : it %4d, rank %4d: proc = %9.3f s, sync = %9.3f (%9.3f + %9.3f), n_sync = %8d (%8d + %8d) (%7.3f / %7.3f), "
+        if (rank == 0) std::printf("%u. %ld; %.7g; %.7g; %.7g\n", iteration, m0s, mu, alpha, sg); // :1906-1908
+        if (rank == 0) std::printf("RESULT : it %4d, rank %4d: proc = %9.3f s, sync = %9.3f (%9.3f + %9.3f), n_sync = %8d (%8d + %8d) (%7.3f / %7.3f), "
                     "betasq = %15.10f, m0 = %10d\n",
                     iteration, rank, t1 - t0, 0.0, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, 0.0, (int)m0s);
         std::fflush(stdout);
@@ -681,8 +763,9 @@ int run_bayesw(const Options& opt_in, int rank, int nranks, int local_rank)
             hg_check(hgibbs_get_residual(dev, eps.data()), "hgibbs_get_residual");
             hg_check(hgibbs_w_get_beta(dev, beta.data(), comp.data()), "hgibbs_w_get_beta");
             pwrite_at(epsf, 0, &iteration, sizeof(unsigned));
-            pwrite_at(epsf, sizeof(unsigned), &Ntot, sizeof(unsigned));
-            pwrite_at(epsf, 2 * sizeof(unsigned), eps.data(), (size_t)Ntot * sizeof(double));
+            const unsigned nloc = hi - lo; // this rank's rows
+            pwrite_at(epsf, sizeof(unsigned), &nloc, sizeof(unsigned));
+            pwrite_at(epsf, 2 * sizeof(unsigned), eps.data(), (size_t)nloc * sizeof(double));
             pwrite_at(mrkf, 0, &iteration, sizeof(unsigned));
             pwrite_at(mrkf, sizeof(unsigned), &Mtot, sizeof(unsigned));
             pwrite_at(mrkf, 2 * sizeof(unsigned), hydraw_chain_order(chain), (size_t)Mtot * sizeof(int));
@@ -791,77 +874,7 @@ int main(int argc, const char* argv[])
     // ---- device -------------------------------------------------------------
     hgibbs_t dev = nullptr;
     hg_check(hgibbs_create(local_rank, &dev), "hgibbs_create");
-    if (nranks > 1) {
-        uint8_t id[128];
-        const std::string idf = base + ".ncclid";
-        if (rank == 0) {
-            hg_check(hgibbs_comm_unique_id(id), "hgibbs_comm_unique_id");
-            FILE* f = std::fopen((idf + ".tmp").c_str(), "wb");
-            if (!f || std::fwrite(id, 1, 128, f) != 128) fatal("FATAL  : can not write " + idf);
-            std::fclose(f);
-            std::rename((idf + ".tmp").c_str(), idf.c_str());
-        } else {
-            FILE* f = nullptr;
-            for (int tries = 0; tries < 6000 && !(f = std::fopen(idf.c_str(), "rb")); ++tries)
-                std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            if (!f || std::fread(id, 1, 128, f) != 128) fatal("FATAL  : can not read " + idf);
-            std::fclose(f);
-        }
-        hg_check(hgibbs_comm_init(dev, nranks, rank, id), "hgibbs_comm_init");
-        // in-launch peer-mailbox exchange: every rank publishes its IPC handle next to the id file
-        uint8_t mine[64];
-        std::vector<uint8_t> all((size_t)nranks * 64);
-        bool p2p_ok = hgibbs_p2p_export(dev, mine) == 0;
-        {
-            const std::string hf = base + ".p2p." + std::to_string(rank);
-            FILE* f = std::fopen((hf + ".tmp").c_str(), "wb");
-            if (f) {
-                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
-                std::fwrite(mine, 1, 64, f);
-                std::fclose(f);
-                std::rename((hf + ".tmp").c_str(), hf.c_str());
-            }
-        }
-        for (int r = 0; r < nranks; ++r) {
-            const std::string hf = base + ".p2p." + std::to_string(r);
-            FILE* f = nullptr;
-            for (int tries = 0; tries < 6000 && !(f = std::fopen(hf.c_str(), "rb")); ++tries)
-                std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            char flag = 'N';
-            if (!f || std::fread(&flag, 1, 1, f) != 1 || std::fread(all.data() + (size_t)r * 64, 1, 64, f) != 64 || flag != 'Y') p2p_ok = false;
-            if (f) std::fclose(f);
-        }
-        if (p2p_ok && hgibbs_p2p_import(dev, all.data()) != 0) p2p_ok = false;
-        // a rank that could not import falls back to RCCL; all ranks must agree, so publish the verdict too
-        {
-            const std::string vf = base + ".p2pok." + std::to_string(rank);
-            FILE* f = std::fopen((vf + ".tmp").c_str(), "wb");
-            if (f) {
-                std::fwrite(p2p_ok ? "Y" : "N", 1, 1, f);
-                std::fclose(f);
-                std::rename((vf + ".tmp").c_str(), vf.c_str());
-            }
-            for (int r = 0; r < nranks; ++r) {
-                const std::string of = base + ".p2pok." + std::to_string(r);
-                FILE* g = nullptr;
-                for (int tries = 0; tries < 6000 && !(g = std::fopen(of.c_str(), "rb")); ++tries)
-                    std::this_thread::sleep_for(std::chrono::milliseconds(10));
-                char flag = 'N';
-                if (!g || std::fread(&flag, 1, 1, g) != 1 || flag != 'Y') p2p_ok = false;
-                if (g) std::fclose(g);
-            }
-        }
-        hg_check(hgibbs_set_option(dev, "p2p", p2p_ok ? 1 : 0), "p2p");
-        if (rank == 0) std::printf("INFO   : per-batch exchange over %s\n", p2p_ok ? "xGMI peer mailboxes (in-launch)" : "RCCL all-reduce");
-        if (rank == 0) {
-            std::this_thread::sleep_for(std::chrono::milliseconds(500));
-            std::remove(idf.c_str());
-            for (int r = 0; r < nranks; ++r) {
-                std::remove((base + ".p2p." + std::to_string(r)).c_str());
-                std::remove((base + ".p2pok." + std::to_string(r)).c_str());
-            }
-        }
-    }
+    if (nranks > 1) setup_ranks(dev, base, rank, nranks);
     if (opt.batch) hg_check(hgibbs_set_option(dev, "batch", opt.batch), "batch");
     if (opt.cpg) hg_check(hgibbs_set_option(dev, "cols_per_group", opt.cpg), "cols_per_group");
 

@@ -43,6 +43,7 @@ struct hydraw_chain {
     std::vector<double> gamma, sum_failure_fix;
     std::vector<unsigned int> xI;
     uint32_t iteration = 0;
+    uint32_t row_begin = 0;
 };
 
 static int wfail(const std::string& m)
@@ -106,7 +107,6 @@ int hydraw_chain_create(hgibbs_t dev, const hydraw_model_desc* model, const doub
     uint32_t n_global = 0, n_local = 0, M = 0, row_begin = 0;
     if (hgibbs_dims(dev, &n_global, &n_local, &M, &row_begin)) return 1;
     if (n_global < 2 || M == 0) return wfail("hydraw_chain_create: load genotypes first (hgibbs_load_bed / hgibbs_synth_bed)");
-    if (n_local != n_global) return wfail("hydraw_chain_create: BayesW runs on one GPU in this build (the handle holds a shard)");
     if (model->K < 2) return wfail("hydraw_chain_create: K must be >= 2 (zero component + at least one mixture)");
     if (hgibbs_w_init(dev, failure_host)) return 1;
     if (hgibbs_w_set_model(dev, model->G, model->K, model->groups, model->mS, model->quad_points)) return 1;
@@ -115,6 +115,7 @@ int hydraw_chain_create(hgibbs_t dev, const hydraw_model_desc* model, const doub
     c->dev = dev;
     c->N = n_global;
     c->M = M;
+    c->row_begin = row_begin;
     c->G = model->G;
     c->K = model->K;
     c->quad = model->quad_points;
@@ -146,7 +147,7 @@ int hydraw_chain_create(hgibbs_t dev, const hydraw_model_desc* model, const doub
     c->alpha = bw::PI_BW / std::sqrt(denominator);
     std::vector<double> eps(n_global);
     for (uint32_t i = 0; i < n_global; ++i) eps[i] = y_host[i] - c->mu; // :823-826
-    if (hgibbs_set_residual(dev, eps.data())) {
+    if (hgibbs_set_residual(dev, eps.data() + row_begin)) { // this rank's rows
         delete c;
         return 1;
     }
@@ -185,7 +186,7 @@ int hydraw_chain_set_covariates(hydraw_chain_t c, const double* X_host, int C)
         for (uint32_t i = 0; i < c->N; ++i) s += X_host[(size_t)i * C + k] * (double)c->fail[i];
         c->sum_failure_fix[k] = s;
     }
-    return hgibbs_set_covariates(c->dev, C ? X_host : nullptr, C);
+    return hgibbs_set_covariates(c->dev, C ? X_host + (size_t)c->row_begin * C : nullptr, C);
 }
 
 /* srand(seed) between iterations: the reference reseeds at every checkpoint (:2029) and after a restart (:877) */
@@ -218,7 +219,7 @@ int hydraw_chain_restore(hydraw_chain_t c, const hydraw_restart_state* st)
     c->rng = st->rng;
     hgibbs_grand_seed(&c->grand, st->ars_seed);
     if (hgibbs_w_set_beta(c->dev, st->beta, st->components)) return 1;
-    if (hgibbs_set_residual(c->dev, st->eps)) return 1;
+    if (hgibbs_set_residual(c->dev, st->eps)) return 1; /* this rank's rows */
     c->iteration = st->iteration + 1;
     return 0;
 }

@@ -187,7 +187,7 @@ int hydra_chain_csv_line(hydra_chain_t c, uint32_t iteration, char* buf, size_t 
 const int32_t* hydra_chain_order(hydra_chain_t c);
 
 /* ======================================================================== */
-/* BayesW: Weibull survival model (src/BayesW.cpp), one GPU                     */
+/* BayesW: Weibull survival model (src/BayesW.cpp); individuals shard as above  */
 /* ======================================================================== */
 /* The libc rand() stream the reference's ARS draws from (src/BayesW_arms.cpp:914-919,
  * srand at src/BayesW.cpp:1012, :877, :2029), one private copy per chain:
@@ -270,7 +270,7 @@ typedef struct {
     const double* pi;          /* G*K */
     const double* beta;        /* M */
     const int32_t* components; /* M */
-    const double* eps;         /* n_global */
+    const double* eps;         /* n_local: this rank's rows */
     const int32_t* order;      /* M */
     const double* gamma;       /* C or NULL */
     const int32_t* xI;         /* C or NULL */

@@ -101,3 +101,77 @@ def test_two_ranks_one_gpu_p2p_exchange(batch):
     eps = np.concatenate([res[0][5], res[1][5]])
     assert np.allclose(eps, dev.get_residual(), rtol=0, atol=1e-9)
     assert res[0][6] == ch.last_nnz()
+
+
+# ---- BayesW sharded the same way: per-batch row sums and the density sums add over the ranks ----------
+def _worker_bw(rank, world, port, bed, y, fail, X, N, iters, q):
+    import torch
+    import torch.distributed as dist
+    from hydra_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = capi.Device(0)
+
+        def allreduce(arr):
+            t = torch.from_numpy(arr.view(np.int64) if arr.dtype == np.uint64 else arr)
+            dist.all_reduce(t)
+
+        dev.comm_init_external(world, rank, allreduce)
+        lo, hi = _shard(N, world, rank)
+        dev.load_bed(bed, N, row_begin=lo, row_end=hi, n_global=N)
+        ch = capi.BwChain(dev, y, fail, seed=1222, quad=9)
+        if X is not None:
+            ch.set_covariates(X)
+        for _ in range(iters):
+            ch.iterate()
+        beta, comp = ch.beta()
+        st = ch.state()
+        q.put((rank, beta, comp, st["mu"], st["alpha"], st["sigmaG"], dev.get_residual(), ch.last_nnz(), ch.gamma()[0] if X is not None else None))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_cov", [False, True])
+def test_bayesw_two_ranks_one_gpu(with_cov):
+    import torch.multiprocessing as mp
+    from hydra_amd import capi, synth
+    M, N, iters = 120, 5000, 3
+    geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.01)
+    y, fail, _ = synth.make_survival(geno, seed=72, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+    X = np.random.default_rng(3).normal(size=(N, 2)) * 0.2 if with_cov else None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bw, args=(r, 2, port, bed, y, fail, X, N, iters, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert len(r) == 9, "rank %s failed: %s" % (r[0], r[1])
+    res.sort(key=lambda r: r[0])
+
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.BwChain(dev, y, fail, seed=1222, quad=9)
+    if with_cov:
+        ch.set_covariates(X)
+    for _ in range(iters):
+        ch.iterate()
+    beta, comp = ch.beta()
+    st = ch.state()
+    tol = lambda a, b: np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-8 * np.maximum(1.0, np.abs(np.asarray(b))))
+    # replicas identical, bit for bit (same all-reduced sums, same generators)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    # equal to the single-rank chain up to the summation tree
+    assert np.array_equal(res[0][2], comp) and tol(res[0][1], beta) and tol(res[0][3], st["mu"]) and tol(res[0][4], st["alpha"])
+    assert tol(res[0][5], st["sigmaG"]) and res[0][7] == ch.last_nnz()
+    assert tol(np.concatenate([res[0][6], res[1][6]]), dev.get_residual())
+    if with_cov:
+        assert tol(res[0][8], ch.gamma()[0])
