@@ -150,3 +150,73 @@ def test_two_rank_sharded_chain_matches_unsharded_oracle():
         assert np.allclose(eps, ref.arr("eps"), rtol=0, atol=1e-9)
     finally:
         L.orc_set_dot_form(0)
+
+
+# ---- BayesW: the per-batch row block and the failure counts add over the ranks ---------------------------
+def _worker_bw(rank, world, port, geno, eps, fail, alpha, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = orc.load()
+    orc._bind_bw(L)
+    M, N = geno.shape
+    lo, hi = shard_rows(N, world, rank)
+    g, e, d = geno[:, lo:hi], eps[lo:hi], fail[lo:hi]
+    # load time: integer counts add over the ranks (n1, n2, nmiss, failures among genotype 1 / 2)
+    cnt = np.stack([(g == 1).sum(1), (g == 2).sum(1), (g == 3).sum(1), ((g == 1) * d).sum(1), ((g == 2) * d).sum(1)], axis=1).astype(np.int64)
+    t = torch.from_numpy(cnt)
+    dist.all_reduce(t)
+    # per batch: the row block rows[2c] = sum vi over genotype 1, rows[2c+1] over genotype 2, last = sum vi
+    vi = np.exp(alpha * e - 0.577215664901532)
+    rows = np.zeros(2 * M + 1)
+    for c in range(M):
+        rows[2 * c] = vi[g[c] == 1].sum()
+        rows[2 * c + 1] = vi[g[c] == 2].sum()
+    rows[2 * M] = vi.sum()
+    r = torch.from_numpy(rows)
+    dist.all_reduce(r)
+    # every rank evaluates the same marginals and picks from the same reduced rows
+    n1, n2, nm, f1, f2 = [cnt[:, k].astype(np.float64) for k in range(5)]
+    mave = (n1 + 2 * n2) / (N - nm)
+    sd = np.sqrt(((N - n1 - n2 - nm) * mave ** 2 + n1 * (1 - mave) ** 2 + n2 * (2 - mave) ** 2) / (N - 1))
+    sumfail = ((f1 + 2 * f2) - mave * fail.sum()) / sd
+    pi, cva = np.array([0.9, 0.06, 0.04]), np.array([0.001, 0.01])
+    mls = np.zeros((M, 3))
+    for c in range(M):
+        ml = np.zeros(3)
+        L.orc_bw_marginals(9, 3, orc.dptr(pi), orc.dptr(cva), alpha, 0.05, float(sumfail[c]), float(rows[2 * M]), float(rows[2 * c + 1]),
+                           float(rows[2 * c]), float(rows[2 * M] - rows[2 * c] - rows[2 * c + 1]), float(mave[c]), float(sd[c]), orc.dptr(ml))
+        mls[c] = ml
+    q.put((rank, cnt, rows, mls))
+    dist.destroy_process_group()
+
+
+def test_bayesw_row_block_allreduce_matches_unsharded():
+    M, N, alpha = 24, 1003, 3.5
+    geno = synth.make_genotypes(M, N, seed=5, missing_rate=0.02)
+    y, fail, _ = synth.make_survival(geno, seed=6, causal_frac=0.1)
+    eps = y - y.mean()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bw, args=(r, 2, port, geno, eps, fail.astype(np.float64), alpha, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=30)
+    # replicas: same bits
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1:], res[1][1:]))
+    # unsharded
+    L = orc.load()
+    ref = orc.BwChain(L, synth.pack_bed_columns(geno), N, y, fail)
+    cnt = res[0][1]
+    n1, n2, nm = [cnt[:, k].astype(np.float64) for k in range(3)]
+    assert np.array_equal((n1 + 2 * n2) / (N - nm), ref.arr("mave"))  # tables from all-reduced integer counts: exact
+    f = fail.astype(np.float64)
+    sumfail = ((cnt[:, 3] + 2 * cnt[:, 4]) - ref.arr("mave") * f.sum()) / ref.arr("msd")
+    assert np.array_equal(sumfail, ref.arr("sum_failure"))
+    vi = np.exp(alpha * eps - 0.577215664901532)
+    want = np.array([[vi[geno[c] == 1].sum(), vi[geno[c] == 2].sum()] for c in range(M)]).ravel()
+    assert np.allclose(res[0][2][:-1], want, rtol=1e-13, atol=0) and abs(res[0][2][-1] - vi.sum()) <= 1e-12 * vi.sum()
+    assert np.all(res[0][3] > 0) and np.all(np.isfinite(res[0][3]))
