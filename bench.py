@@ -169,6 +169,16 @@ def exchange_self_check(capi, dist, world, rank, local_rank):
     return bool(int(t[0]))
 
 
+def cpu_model():
+    try:
+        lines = open("/proc/cpuinfo").read().splitlines()
+        name = next(l.split(":", 1)[1].strip() for l in lines if l.startswith("model name"))
+        sockets = len({l.split(":", 1)[1].strip() for l in lines if l.startswith("physical id")}) or 1
+        return "%s, %d socket(s), %d logical CPUs visible" % (name, sockets, len(os.sched_getaffinity(0)))
+    except Exception:
+        return "unknown"
+
+
 def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
     """The oracle (CPU restatement of hydra's path: LUT + AVX2 dot, OpenMP over
     individuals as the reference's loops are, its bookkeeping passes) timed on a
@@ -190,7 +200,7 @@ def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
                 if out.returncode == 0:
                     r = json.loads(out.stdout.strip().splitlines()[-1])
                     flags = "-O3 -march=native -fopenmp" if lib_name == "liboracle_omp.so" else "-O2"
-                    return {"value": r["markers_per_s"], "unit": "markers/s", "cores": thr, "kind": "port",
+                    return {"value": r["markers_per_s"], "unit": "markers/s", "cores": thr, "kind": "port", "cpu": cpu_model(),
                             "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
                                       "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, %s"
                                       % (ms, M, N, lib_name, flags)}
@@ -231,7 +241,7 @@ def cpu_baseline_bw(dev, y, fail, N, M, mS, quad, sample_markers):
                                  capture_output=True, text=True, timeout=900)
             if out.returncode == 0:
                 r = json.loads(out.stdout.strip().splitlines()[-1])
-                return {"value": r["markers_per_s"], "unit": "markers/s", "cores": 1, "kind": "port",
+                return {"value": r["markers_per_s"], "unit": "markers/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
                         "sample": "restated hydra BayesW sampler (sequential sums, libm exp, ARS), first %d of %d markers, N=%d, "
                                   "1 Gibbs iteration after 1 warm-up, liboracle.so, -O2" % (ms, M, N)}
             print("cpu_baseline (bayesw) failed (rc %d): %s" % (out.returncode, out.stderr[-400:]), file=sys.stderr)
@@ -380,10 +390,12 @@ def main():
         chain.iterate()
 
     sync()
-    stats = []
+    stats, step_s = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         chain.iterate()  # returns only after the sweep's stream has drained
+        step_s.append(time.perf_counter() - ts)
         stats.append((dev.sweep_stats(), chain.last_nnz()))
     sync()
     dt = time.perf_counter() - t0
@@ -412,6 +424,7 @@ def main():
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_best": min(step_s) * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -428,6 +441,12 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
                          "sweep_ms_per_iter": sweep_ms / K},
         }
+        try:  # measured streaming ceiling beside the nominal peak: 2 GiB device copy, far beyond the Infinity Cache
+            ceiling = dev.stream_ceiling(2 << 30, 10)
+            out["roofline"]["measured_stream_GBps"] = ceiling
+            out["roofline"]["frac_of_measured_stream"] = achieved / ceiling
+        except Exception as e:
+            print("stream ceiling not measured: %r" % (e,), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU
             sample = args.cpu_sample or max(64, min(M, int(4.0e9 / max(1, N))))

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_covariates", "hgibbs_cov_dot", "hgibbs_cov_update",
     "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_components", "hydra_chain_restore",
     "hydra_rng_to_boost_words", "hydra_rng_from_boost_words", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
-    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hydra_chain_create",
+    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hgibbs_stream_ceiling", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
     # BayesW
@@ -132,6 +132,7 @@ def lib():
     L.hgibbs_sweep.argtypes = [vp, ip, C.c_double, dp, dp, u8p, C.POINTER(RngState), ip, u64p]
     L.hgibbs_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.hgibbs_last_sweep_stats.argtypes = [vp, C.POINTER(SweepStats)]
+    L.hgibbs_stream_ceiling.argtypes = [vp, C.c_uint64, C.c_int, dp]
     L.hydra_chain_create.argtypes = [vp, C.POINTER(ModelDesc), dp, C.POINTER(vp)]
     L.hydra_chain_destroy.argtypes = [vp]
     L.hydra_chain_iterate.argtypes = [vp]
@@ -343,6 +344,11 @@ class Device:
         out = np.zeros(self.G)
         check(self.L.hgibbs_beta_sqnorm(self.h, _dp(out)))
         return out
+
+    def stream_ceiling(self, nbytes=2 << 30, reps=10):
+        out = C.c_double()
+        check(self.L.hgibbs_stream_ceiling(self.h, nbytes, reps, C.byref(out)))
+        return out.value
 
     def set_option(self, name, value):
         check(self.L.hgibbs_set_option(self.h, name.encode(), int(value)))

@@ -1059,6 +1059,27 @@ int hgibbs_debug_times(hgibbs_t h, uint64_t* out8)
     return 0;
 }
 
+int hgibbs_stream_ceiling(hgibbs_t h, uint64_t bytes, int reps, double* gbps)
+{
+    if (!h || !gbps || bytes < (1u << 20) || reps < 1) return fail("hgibbs_stream_ceiling: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc(&a, bytes));
+    HIP_TRY(hipMalloc(&b, bytes));
+    HIP_TRY(hipMemsetAsync(a, 1, bytes, h->stream));
+    HIP_TRY(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, h->stream)); // warm-up
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) HIP_TRY(hipMemcpyAsync((i & 1) ? a : b, (i & 1) ? b : a, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    HIP_TRY(hipFree(a));
+    HIP_TRY(hipFree(b));
+    *gbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out)
 {
     if (!h || !out) return fail("null argument");

@@ -154,6 +154,9 @@ typedef struct {
     double kernel_ms_avg; /* average duration of the dominant kernel's launches */
 } hgibbs_sweep_stats;
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
+/* measured streaming ceiling of this GPU: device-to-device copy of `bytes` (choose well above the 256 MB
+ * Infinity Cache), `reps` times; GB/s counts bytes read + bytes written */
+int hgibbs_stream_ceiling(hgibbs_t h, uint64_t bytes, int reps, double* gbps);
 
 /* ======================================================================== */
 /* Host driver: the body of BayesRRm::runMpiGibbs (src/BayesRRm.cpp:933-2939)
