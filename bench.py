@@ -179,6 +179,16 @@ def cpu_model():
         return "unknown"
 
 
+def reference_probe():
+    """hydra itself is the preferred CPU baseline if Eigen 3.3.x and Boost >= 1.67 headers
+    are on the box; probe, do not assume."""
+    roots = ["/usr/include", "/usr/local/include", "/opt/conda/include", "/usr/include/eigen3", "/opt/rocm/include"]
+    eigen = [r for r in roots if os.path.exists(os.path.join(r, "Eigen", "Eigen"))]
+    boost = [r for r in roots if os.path.exists(os.path.join(r, "boost", "random.hpp"))]
+    return "Eigen headers: %s; Boost.Random headers: %s => hydra itself %s be built here" % (
+        eigen or "absent", boost or "absent", "could" if eigen and boost else "cannot")
+
+
 def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
     """The oracle (CPU restatement of hydra's path: LUT + AVX2 dot, OpenMP over
     individuals as the reference's loops are, its bookkeeping passes) timed on a
@@ -201,6 +211,7 @@ def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
                     r = json.loads(out.stdout.strip().splitlines()[-1])
                     flags = "-O3 -march=native -fopenmp" if lib_name == "liboracle_omp.so" else "-O2"
                     return {"value": r["markers_per_s"], "unit": "markers/s", "cores": thr, "kind": "port", "cpu": cpu_model(),
+                            "reference_probe": reference_probe(),
                             "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
                                       "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, %s"
                                       % (ms, M, N, lib_name, flags)}
