@@ -8,7 +8,7 @@ BASELINE.json's metric is quoted on: N = 500 000 individuals, M = 1 000 000
 markers (125 GB of packed .bed resident in HBM); at --gpus G the individuals
 are sharded G ways ("strong" scaling: total work fixed).
 
-    python bench.py --gpus 1 --steps 3 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
@@ -317,7 +317,7 @@ def main_bayesw(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10, help="timed iterations (BASELINE.md section 4: iterations 2-11 after 2 warm-up ones)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS) + sorted(BW_CONFIGS))
     ap.add_argument("--N", type=int, default=0, help="override individuals")

@@ -8,6 +8,7 @@ import bench
 cfg, batch, cpg = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 N, M, G, mS = bench.CONFIGS[cfg]
 if len(sys.argv) > 4: M = int(sys.argv[4])
+if os.environ.get("DBG_N"): N = int(os.environ["DBG_N"])
 slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ext = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 max_seg = int(sys.argv[7]) if len(sys.argv) > 7 else 0
