@@ -1255,17 +1255,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             for (int i = 0; i < n; i += GRAPH_N) HIP_TRY(hipGraphLaunch(gexec, h->stream));
         }
         for (int i = 0; i < n && !gexec; ++i) {
-            if (tier == 4) {
-                if (cpg == 4) k_sweep_batch<4, 4><<<grid, BLOCK, lds, h->stream>>>(p);
-                else k_sweep_batch<8, 4><<<grid, BLOCK, lds, h->stream>>>(p);
-            } else {
-                switch (cpg) {
-                case 2: k_sweep_batch<2, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-                case 4: k_sweep_batch<4, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-                case 8: k_sweep_batch<8, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-                default: k_sweep_batch<16, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-                }
-            }
+            launch_one();
             if (split) {
                 if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
                 if (tier == 4) k_sweep_draw<4><<<1, BLOCK, lds, h->stream>>>(p);
