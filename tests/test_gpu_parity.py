@@ -857,3 +857,28 @@ def test_sampler_recovers_the_simulated_model():
     scale = np.sqrt(((y - y.mean()) ** 2).sum() / (N - 1))  # the chain works on the standardised phenotype
     assert np.corrcoef(post, beta_true / scale)[0, 1] > 0.85
     assert 0.35 < np.mean(h2) < 0.65
+
+
+def test_three_hundred_iterations_stay_on_the_oracle(oracle):
+    """A long grouped chain with missing calls: 300 iterations, components identical in every one of them, the
+    generator in the same state at the end, effects within the tolerance throughout (the BayesR chain does not
+    amplify rounding differences the way the ARS-driven BayesW chain does)."""
+    M, N, iters = 3000, 2500, 300
+    geno = synth.make_genotypes(M, N, seed=77, missing_rate=0.01)
+    y, _ = synth.make_phenotype(geno, seed=78, causal_frac=0.03)
+    bed = synth.pack_bed_columns(geno)
+    groups = (np.arange(M) % 3 == 0).astype(np.int32)
+    mS = np.array([[0.0, 0.0001, 0.001, 0.01], [0.0, 0.001, 0.01, 0.1]])
+    ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=99)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=99)
+    for it in range(iters):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, _ = dev.get_beta()
+        assert np.array_equal(comp, ref.arr("components")), it
+        assert close(beta, ref.arr("beta")), it
+    st = ch.state()
+    rx, ridx = ref.rng_state()
+    assert _same_stream(st["rng_x"], st["rng_idx"], rx, ridx) and close(st["sigmaE"], ref.sigmaE) and close(st["sigmaG"], ref.arr("sigmaG"))
