@@ -53,7 +53,8 @@ constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
 constexpr int MAX_SEG = 4;               // segments per launch: each ends on a predicted event (its pivot) and hands one pending update on
-constexpr int NROW = NSUM + MAX_SEG - 1; // rows per batch column: s1, s2, integer Gram terms with the pivots of the earlier segments
+constexpr int NROW = NSUM + 4;           // most rows per batch column: s1, s2 and either one Gram term per earlier pivot (MAX_SEG - 1) or, in the
+                                         // two-segment build that carries missing calls through the extension, the four terms A, B, C, D
 constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // partial rows per slice (padded)
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS

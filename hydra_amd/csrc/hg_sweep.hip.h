@@ -227,12 +227,12 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
 // with A_jq = sum_i gw_j gw_q the integer Gram term accumulated by the streaming loop.
 // Runs in ONE workgroup of 256 threads.
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
-template <int SEG>
+template <int SEG, int MG>
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const DescHead& d, const uint32_t (&nbs)[SEG],
                                                  const SweepShared& sh)
 {
     const int tid = threadIdx.x;
-    constexpr int NR = NSUM + SEG - 1; // rows per batch column at this tier
+    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1); // rows per batch column at this tier
     const int K = p.K;
     const uint32_t nb = nbs[SEG - 1];
     const uint32_t idx0 = d.rng_idx;
@@ -282,8 +282,17 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if ((uint32_t)tid >= lo && (uint32_t)tid < hi && mm.ada) {
             double num = sh.dp[tid];
             for (int q = 0; q < seg; ++q) { // Gram corrections for the earlier pivots' updates, in order
-                const double A = sh.tot[NR * tid + NSUM + q];
-                const double xx = mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1]));
+                double xx;
+                if constexpr (MG) {
+                    // missing calls in either column: x_j'x_p = mstd_j mstd_p (A - m_p B - m_j C + m_j m_p D) with the integer sums
+                    // A = sum gw_j gw_p, B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p (gw = genotype * non-missing)
+                    const double* r = sh.tot + NR * tid + NSUM + 4 * q;
+                    const double mp = sh.ev[3 * q + 1];
+                    xx = mm.mstd * sh.ev[3 * q + 2] * (((r[0] - mp * r[1]) - mm.mave * r[2]) + (mm.mave * mp) * r[3]);
+                } else {
+                    const double A = sh.tot[NR * tid + NSUM + q];
+                    xx = mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1]));
+                }
                 num += sh.ev[3 * q] * xx;
             }
             num += mm.bold * p.n_minus_1;
@@ -479,7 +488,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if (e0 != 0xffffffffu) {
             want[0] = e0 + 1u;
             // a pivot whose own column has missing calls cannot be corrected for: (any & ~ev) cannot tell, so read its flag
-            bool chain = p.gram && !(sh.scanf[naccept + e0] & 2u);
+            bool chain = p.gram && (MG || !(sh.scanf[naccept + e0] & 2u));
             const uint32_t lim = (want[0] + p.ext_limit < cap) ? want[0] + p.ext_limit : cap;
             for (int q = 1; q < MAX_SEG; ++q) {
                 want[q] = want[q - 1];
@@ -487,11 +496,11 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                     chain = false;
                     continue;
                 }
-                const uint32_t e = first_set(many, want[q - 1], lim);
+                const uint32_t e = MG ? first_set(mev, want[q - 1], lim) : first_set(many, want[q - 1], lim);
                 if (e == 0xffffffffu) { // no further event in reach: run to the limit, nothing can follow
                     want[q] = lim;
                     chain = false;
-                } else if (sh.scanf[naccept + e] & 2u) { // a column with missing calls stays out of the extension
+                } else if (!MG && (sh.scanf[naccept + e] & 2u)) { // a column with missing calls stays out of the extension
                     want[q] = e;
                     chain = false;
                 } else {
@@ -633,10 +642,11 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
 // (4 wave tiles = 4096 individuals each).  Every lane keeps the sums of its
 // columns in registers across all its tiles; one wave/block reduction per
 // launch, then per-slice partial rows for the last arriver.
-template <int CPG, int SEG>
+template <int CPG, int SEG, int MG>
 __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
-    constexpr int NR = NSUM + SEG - 1; // rows per batch column: s1, s2 and one Gram term per earlier pivot
+    static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
+    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1); // rows per batch column: s1, s2 and the Gram terms
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
@@ -769,12 +779,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 for (int q = 0; q < SEG; ++q)
                     if (q < npend) wpn[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tilen << 8) + voff);
             }
-            uint32_t gwp[SEG - 1];
+            uint32_t gwp[SEG - 1], nmp[SEG - 1];
 #pragma unroll
             for (int q = 0; q < SEG - 1; ++q) {
-                uint32_t nmp;
-                gwp[q] = 0u;
-                if (q < ng) code_weights(wpiv[q], gwp[q], nmp);
+                gwp[q] = nmp[q] = 0u;
+                if (q < ng) code_weights(wpiv[q], gwp[q], nmp[q]);
             }
             if (pend) { // the previous launch's event(s), in order
 #pragma unroll
@@ -811,6 +820,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 }
                 if (cseg[c] > 0) {
                     uint32_t g = gram16(gw[c], gwp[0]);
+                    if constexpr (MG) { // B, C, D: popcounts on the bit planes (weights 1 and 2 of the 2-bit fields)
+                        const uint32_t lj = gw[c] & 0x55555555u, hj = (gw[c] >> 1) & 0x55555555u;
+                        const uint32_t lp = gwp[0] & 0x55555555u, hp = (gwp[0] >> 1) & 0x55555555u;
+                        g |= ((uint32_t)__popc(lj & nmp[0]) + 2u * (uint32_t)__popc(hj & nmp[0])) << 16;
+                        ag2[c] += ((uint32_t)__popc(nm[c] & lp) + 2u * (uint32_t)__popc(nm[c] & hp)) | ((uint32_t)__popc(nm[c] & nmp[0]) << 16);
+                    }
                     if constexpr (SEG > 2) {
                         if (cseg[c] > 1) g |= gram16(gw[c], gwp[1]) << 16;
                         if (cseg[c] > 2) ag2[c] += gram16(gw[c], gwp[SEG > 3 ? 2 : 0]);
@@ -835,8 +850,9 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
             // exact: integers far below 2^53
             const double g0 = any_gram ? wave_sum((double)(ag01[c] & 0xffffu)) : 0.0;
-            const double g1 = ng > 1 ? wave_sum((double)(ag01[c] >> 16)) : 0.0;
-            const double g2 = ng > 2 ? wave_sum((double)ag2[c]) : 0.0;
+            const double g1 = (MG ? any_gram : ng > 1) ? wave_sum((double)(ag01[c] >> 16)) : 0.0;
+            const double g2 = MG ? (any_gram ? wave_sum((double)(ag2[c] & 0xffffu)) : 0.0) : (ng > 2 ? wave_sum((double)ag2[c]) : 0.0);
+            const double g3 = (MG && any_gram) ? wave_sum((double)(ag2[c] >> 16)) : 0.0;
             if (lane == 0) {
                 double* wp_ = sh.wpart + wave * sh.wstride + NR * c;
                 wp_[0] = t1;
@@ -844,6 +860,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 wp_[2] = g0;
                 if constexpr (NR > 3) wp_[3] = g1;
                 if constexpr (NR > 4) wp_[4] = g2;
+                if constexpr (NR > 5) wp_[5] = g3;
             }
         }
         if (first_group) {
@@ -955,14 +972,14 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         }
         return;
     }
-    sweep_draw_phase<SEG>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG>(p, d, nbs, sh);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
-template <int SEG>
+template <int SEG, int MG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
-    constexpr int NR = NSUM + SEG - 1;
+    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1);
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
@@ -980,7 +997,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
     if (threadIdx.x == 0) sh.tot[NR * sh.bcap] = p.sums_out[NR * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase<SEG>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG>(p, d, nbs, sh);
 }
 
 } // namespace hg

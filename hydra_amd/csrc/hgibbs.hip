@@ -81,6 +81,9 @@ struct hgibbs_ctx {
     double *mave = nullptr, *mstd = nullptr;
     unsigned long long* counts = nullptr; // 3*M: n1, n2, nmiss (global after all-reduce)
     bool have_stats = false;
+    bool any_missing = false; // some column has missing calls
+    double missing_col_frac = 0.0; // fraction of columns with missing calls (decides which build of the sweep kernel runs)
+    int gram_missing = -1; // carry columns with missing calls through the extension: -1 auto, 0 never, 1 whenever possible
 
     // covariates: C columns of n_pad doubles in the permuted eps layout
     double* covX = nullptr;
@@ -775,6 +778,14 @@ static int compute_stats(hgibbs_ctx* h)
     k_stats<<<(h->M + 255) / 256, 256, 0, h->stream>>>(h->counts, h->n_global, h->mave, h->mstd, h->M);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+        std::vector<unsigned long long> c((size_t)h->M * 3);
+        HIP_TRY(hipMemcpy(c.data(), h->counts, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        uint64_t nmc = 0;
+        for (uint32_t i = 0; i < h->M; ++i) nmc += c[3ull * i + 2] != 0 ? 1u : 0u;
+        h->any_missing = nmc != 0;
+        h->missing_col_frac = (double)nmc / (double)h->M;
+    }
     h->have_stats = true;
     return 0;
 }
@@ -1021,6 +1032,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "slices")) {
         if (value < 0 || value > S_CAP) return fail("slices must be in [0,%d] (0 = auto)", S_CAP);
         h->slices = (uint32_t)value;
+    } else if (!std::strcmp(name, "gram_missing")) {
+        h->gram_missing = (int)value;
     } else if (!std::strcmp(name, "graph")) {
         h->use_graph = value != 0;
     } else if (!std::strcmp(name, "max_seg")) {
@@ -1192,9 +1205,16 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.max_seg = h->max_seg ? std::min<uint32_t>(h->max_seg, MAX_SEG) : ((h->n_local <= (h->nranks > 1 ? 150000u : 100000u)) ? 4u : 2u);
     // two builds of the kernel: tier 2 (one Gram term, two pending updates: lean registers, 3 workgroups per CU) and
     // tier 4 (three Gram terms, four pending updates; cols_per_group 4 or 8 only)
-    const int tier = (p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
+    // data with missing calls: the two-segment build that carries the four Gram terms (A, B, C, D) takes such columns
+    // through the extension; the four-segment build would stop its chain at the first of them
+    // (that costs three more popcount sums per extension column and word, and a column with missing calls needs its own
+    // s2 pass anyway: measured +10 % at N = 100 K whatever the share of such columns, -12 % at N = 500 K when every column
+    // has missing calls, where the streaming loop dominates the launch)
+    const bool mg_wanted = h->gram_missing > 0 || (h->gram_missing < 0 && (h->missing_col_frac <= 0.25 || h->n_local <= 250000u));
+    const bool mg = mg_wanted && h->gram && h->any_missing && cpg == 8 && (h->max_seg == 0 || h->max_seg == 2);
+    const int tier = (!mg && p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
-    const int nr = NSUM + tier - 1;
+    const int nr = NSUM + (tier - 1) * (mg ? 4 : 1);
     // the Gram partials are 16-bit fields per lane (64 per tile at most): with S >= 768 / (batch / cpg) slices a lane
     // sees ntg / S tiles -- refuse the chain of segments where that could overflow
     {
@@ -1221,15 +1241,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const dim3 grid(S * ngroups);
     uint64_t total_launches = 0;
     auto launch_one = [&]() {
-        if (tier == 4) {
-            if (cpg == 4) k_sweep_batch<4, 4><<<grid, BLOCK, lds, h->stream>>>(p);
-            else k_sweep_batch<8, 4><<<grid, BLOCK, lds, h->stream>>>(p);
+        if (mg) {
+            k_sweep_batch<8, 2, 1><<<grid, BLOCK, lds, h->stream>>>(p);
+        } else if (tier == 4) {
+            if (cpg == 4) k_sweep_batch<4, 4, 0><<<grid, BLOCK, lds, h->stream>>>(p);
+            else k_sweep_batch<8, 4, 0><<<grid, BLOCK, lds, h->stream>>>(p);
         } else {
             switch (cpg) {
-            case 2: k_sweep_batch<2, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 4: k_sweep_batch<4, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 8: k_sweep_batch<8, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            default: k_sweep_batch<16, 2><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 2: k_sweep_batch<2, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 4: k_sweep_batch<4, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            case 8: k_sweep_batch<8, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
+            default: k_sweep_batch<16, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
             }
         }
     };
@@ -1258,8 +1280,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             launch_one();
             if (split) {
                 if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
-                if (tier == 4) k_sweep_draw<4><<<1, BLOCK, lds, h->stream>>>(p);
-                else k_sweep_draw<2><<<1, BLOCK, lds, h->stream>>>(p);
+                if (mg) k_sweep_draw<2, 1><<<1, BLOCK, lds, h->stream>>>(p);
+                else if (tier == 4) k_sweep_draw<4, 0><<<1, BLOCK, lds, h->stream>>>(p);
+                else k_sweep_draw<2, 0><<<1, BLOCK, lds, h->stream>>>(p);
             }
         }
         total_launches += (uint64_t)n;

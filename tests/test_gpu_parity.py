@@ -212,6 +212,39 @@ def test_gram_extension_matches_oracle_and_plain_path(oracle, batch):
         assert fewer, "the extension never saved a launch: it is not being exercised"
 
 
+@pytest.mark.parametrize("col_frac", [0.2, 1.0])
+def test_missing_calls_ride_through_the_extension(oracle, col_frac):
+    """Columns with missing calls inside the Gram-corrected extension (the four-term build, option gram_missing):
+    same chain as the oracle and as the build that ends the extension at such columns, in fewer launches."""
+    M, N = 1200, 3000
+    rng = np.random.default_rng(9)
+    geno = synth.make_genotypes(M, N, seed=29, missing_rate=0.0)
+    for c in rng.choice(M, size=int(col_frac * M), replace=False):
+        geno[c, rng.random(N) < 0.02] = 3
+    y, _ = synth.make_phenotype(geno, seed=30, causal_frac=0.03)
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, seed=8)
+    launches = {}
+    for mg in (0, 1):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("max_seg", 2)
+        dev.set_option("batch", 256)
+        dev.set_option("gram_missing", mg)
+        ch = capi.Chain(dev, y, seed=8)
+        tot = 0
+        for it in range(6):
+            if mg:
+                ref.iterate()
+            ch.iterate()
+            tot += dev.sweep_stats()["launches"]
+            if mg:
+                beta, comp, _ = dev.get_beta()
+                assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta")) and close(dev.get_residual(), ref.arr("eps"))
+        launches[mg] = tot
+    assert launches[1] < launches[0]
+
+
 def test_graph_replay_is_the_same_chain():
     """The sweep's launches replayed from a captured HIP graph (option "graph") walk the very same chain."""
     M, N = 900, 3000
