@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
                     help="per-batch cross-GPU exchange: in-launch peer mailboxes, RCCL all-reduce, or self-checked choice")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (hgibbs_set_option), repeatable: option scans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="markers in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -380,6 +381,9 @@ def main():
         dev.set_option("max_seg", args.max_seg)
     if args.graph >= 0:
         dev.set_option("graph", args.graph)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        dev.set_option(name, int(val))
 
     t_setup = time.perf_counter()
     dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)
@@ -445,7 +449,8 @@ def main():
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
                        "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
-                       "launches_per_iter": launches / K, "setup_s": t_setup},
+                       "launches_per_iter": launches / K, "setup_s": t_setup,
+                       **({"missing_rate": args.missing} if args.missing else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (256 if (hi - lo) >= 200000 or world > 1 else 128), world),
                          "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,

@@ -132,6 +132,7 @@ struct SweepParams {
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)
     uint32_t slices_max;     // most tile-group slices a launch may use (<= S_CAP)
+    uint32_t resident;       // workgroups of this kernel build that are co-resident on the device (registers and LDS)
     uint32_t ext_limit;      // longest Gram-corrected extension past the first pivot
     uint32_t max_seg;        // segments a launch may plan (1..MAX_SEG)
     // multi-GPU: when non-null the kernel stops after the local reduction and
@@ -237,6 +238,19 @@ __device__ __forceinline__ void apply_update16(uint32_t w, double v0, double v1,
         uint32_t c = (w >> (2 * s)) & 3u;
         double v = (c == 3u) ? v0 : ((c == 2u) ? v1 : ((c == 0u) ? v2 : 0.0));
         e[s] = e[s] + (0.0 + v);
+    }
+}
+
+// a8 inside the sweep: the same addends from a 16-entry table in LDS indexed by a PAIR of codes (4 bits of the column
+// dword): field extract, one 16-byte LDS read and two adds per two individuals instead of a chain of selects.
+// tab[c1 << 2 | c0] = (0.0 + v[c0], 0.0 + v[c1]); all lanes read the same 256 bytes (one entry per 4 banks: broadcast).
+__device__ __forceinline__ void apply_update16_lds(uint32_t w, const double2* tab, double (&e)[IPT])
+{
+#pragma unroll
+    for (int s = 0; s < IPT; s += 2) {
+        const double2 v = tab[(w >> (2 * s)) & 15u];
+        e[s] = e[s] + v.x;
+        e[s + 1] = e[s + 1] + v.y;
     }
 }
 

@@ -60,12 +60,12 @@ struct SweepShared {
     double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns (+ sum of eps)
     double* tot;       // NROW*bcap + 1 reduced sums
     double* thr;       // [bcap][K-1]
-    double* muk;       // [bcap][K]
     double* logl;      // [bcap][K]
     double* bold;      // [bcap]
     double* mave;
     double* mstd;
-    double* dp;        // [bcap] x_j'eps as reduced from the dots (before corrections)
+    double* dp;        // [bcap] x_j'eps as reduced from the dots; once a column's posterior is evaluated, its full numerator
+                       // (Gram corrections and the old effect's term included): mu_k = dp / denom_k is recomputed by the drawing lane
     int32_t* marker;
     int32_t* grp;
     uint32_t* flags;   // see F_* below
@@ -75,12 +75,15 @@ struct SweepShared {
     double* htab;      // 4 x HT_LDS staged hyper tables (denom, logpi, hlog, sdk) when G*K <= HT_LDS
     double* red;       // 128 doubles: exchange buffer of the tail reduction
     double* ev;        // 3 per segment: (dbeta, mave, mstd) of the event that ended it
-    double* pvl;       // 3*MAX_SEG: update constants of the pending events (kept out of scalar registers)
+    double* pvl;       // 3*MAX_SEG: update constants of the events this launch hands on (draw phase)
+    double2* pvt;      // [MAX_SEG][16]: the pending updates as a table over a PAIR of 2-bit codes (see apply_update16_lds); shares
+                       // its 1 KiB with `red` (the table is dead once the streaming loop is over)
     int32_t* pmk;      // MAX_SEG: markers of the events this launch hands on
     uint8_t* scanf;    // 2*BLOCK flag bytes of the sweep positions after the cursor (bit 0 predicted event, bit 1 missing calls)
     uint32_t wstride;  // NROW*cpg + 1
     uint32_t bcap;     // batch capacity of this launch
 };
+static_assert(MAX_SEG * 16 * 16 <= 128 * 8, "the update table shares the exchange buffer");
 enum { F_LAST = 0, F_POS = 1, F_P2PTMO = 2, F_NACC = 3, F_STOP = 4, F_FPOS = 5, F_FMARK = 6, F_ERR = 7 };
 
 constexpr size_t EPS_STAGE_BYTES = (size_t)BLOCK_WAVES * TILE * sizeof(double); // one wave tile of eps per wave (LDS-DMA target)
@@ -89,7 +92,7 @@ __host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K, int
 {
     size_t n = 0;
     n += (size_t)(nr * bcap + 1) * 8;                                                       // tot
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * K * 8 + (size_t)bcap * 8;            // thr, muk, logl, dp
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)bcap * K * 8 + (size_t)bcap * 8;                // thr, logl, dp
     return (n + 15) & ~(size_t)15;
 }
 
@@ -125,7 +128,8 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
-    sh.red = reinterpret_cast<double*>(q); q += 128 * 8;
+    sh.red = reinterpret_cast<double*>(q);
+    sh.pvt = reinterpret_cast<double2*>(q); q += 128 * 8; // MAX_SEG * 16 * 16 bytes: the streaming loop's table, then the tail's exchange buffer
     sh.ev = reinterpret_cast<double*>(q); q += 16 * 8;
     sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
     sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
@@ -144,7 +148,6 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.estage = q; // union starts here
     sh.tot = reinterpret_cast<double*>(q); q += (size_t)(nr * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
-    sh.muk = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
     sh.dp = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.bcap = bcap;
@@ -311,10 +314,9 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                 }
             }
             sh.logl[tid * K] = lpi[0];
-            sh.muk[tid * K] = 0.0;
+            sh.dp[tid] = num; // each column is evaluated once (in its own segment): the slot is free for the drawing lane
             for (int k = 1; k < K; ++k) {
                 double mk = num / den[k];
-                sh.muk[tid * K + k] = mk;
                 sh.logl[tid * K + k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
             }
         }
@@ -382,7 +384,8 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                     LdsGen g{sh.mt, pos + jeff + 1u, need_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
                     ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
                     const double sd = (p.GK <= HT_LDS) ? sh.htab[3 * HT_LDS + grp * K + k] : p.sdk[(size_t)grp * K + k];
-                    bnew = norm_rng_sd(g, zt, sh.muk[j * K + k], sd);
+                    const double den = (p.GK <= HT_LDS) ? sh.htab[grp * K + k] : p.denom[(size_t)grp * K + k];
+                    bnew = norm_rng_sd(g, zt, sh.dp[j] / den, sd); // the same division the posterior made
                     consumed = g.pos - (pos + jeff + 1u);
                     gerr = g.err;
                 }
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
     // slices actually used: keep the active workgroups co-resident (3 per CU at this register
     // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
-    constexpr uint32_t RES = (CPG >= 16 || SEG > 2) ? 512u : 768u; // co-resident workgroups at this instantiation's register budget
+    const uint32_t RES = p.resident; // co-resident workgroups of this build at this launch's LDS size (occupancy query on the host)
     const uint32_t S = (RES / nactive) < p.slices_max ? ((RES / nactive) ? RES / nactive : 1u) : p.slices_max;
     if (blockIdx.x >= S * nactive) return;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
@@ -683,7 +686,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     // streaming loop (any of them may turn out to be the last arriver)
     if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
     if (!p.sums_out) stage_rng(p, sh, tid);
-    if (pend && tid < 3 * SEG) sh.pvl[tid] = p.desc->pv[tid / 3][tid % 3];
+    if (pend && tid < 16 * SEG) { // entry (c1 << 2 | c0) of pending update q: the addends of two neighbouring individuals
+        const int q = tid >> 4;
+        const double* pv = p.desc->pv[q];
+        auto addend = [&](uint32_t c) { return 0.0 + ((c == 3u) ? pv[0] : ((c == 2u) ? pv[1] : ((c == 0u) ? pv[2] : 0.0))); };
+        sh.pvt[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
+    }
     if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[0] = wall_clock64();
     const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
 
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
 #pragma unroll
     for (int q = 0; q < SEG; ++q) pendp[q] = p.bed + (size_t)(q < npend ? d.pend_marker[q] : 0) * p.stride;
 
-    if (pend) __syncthreads(); // sh.pvl is staged
+    if (pend) __syncthreads(); // sh.pvt is staged
     {
         // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces --
         // exactly the permuted eps layout) one tile ahead of the arithmetic; column dwords of the
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             if (pend) { // the previous launch's event(s), in order
 #pragma unroll
                 for (int q = 0; q < SEG; ++q)
-                    if (q < npend) apply_update16(wp[q], sh.pvl[3 * q], sh.pvl[3 * q + 1], sh.pvl[3 * q + 2], e);
+                    if (q < npend) apply_update16_lds(wp[q], sh.pvt + 16 * q, e);
                 if (first_group) store_eps16(eps_out, tile, lane, e);
             }
             if (first_group) {

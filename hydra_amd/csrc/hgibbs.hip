@@ -57,6 +57,7 @@ static void bw_free(BwState* b);
 
 struct hgibbs_ctx {
     int device = 0;
+    int num_cu = 256;
     BwState* bw = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -510,6 +511,7 @@ int hgibbs_create(int device_id, hgibbs_t* out)
         return fail("hgibbs_create: device %d is %s, this library is built for gfx950 only", device_id, prop.gcnArchName);
     hgibbs_ctx* h = new hgibbs_ctx();
     h->device = device_id;
+    h->num_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
@@ -1215,13 +1217,6 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const int tier = (!mg && p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
     const int nr = NSUM + (tier - 1) * (mg ? 4 : 1);
-    // the Gram partials are 16-bit fields per lane (64 per tile at most): with S >= 768 / (batch / cpg) slices a lane
-    // sees ntg / S tiles -- refuse the chain of segments where that could overflow
-    {
-        const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(h->slices ? h->slices : S_CAP, h->n_pad / BLOCK_IND),
-                                                                           (cpg >= 16 ? 512u : 768u) / std::max<uint32_t>(1u, ngroups)));
-        if (((h->n_pad / BLOCK_IND) + s_min - 1) / s_min > 1000u) p.gram = 0;
-    }
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K, nr);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
@@ -1240,21 +1235,37 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.slices_max = S;
     const dim3 grid(S * ngroups);
     uint64_t total_launches = 0;
-    auto launch_one = [&]() {
-        if (mg) {
-            k_sweep_batch<8, 2, 1><<<grid, BLOCK, lds, h->stream>>>(p);
-        } else if (tier == 4) {
-            if (cpg == 4) k_sweep_batch<4, 4, 0><<<grid, BLOCK, lds, h->stream>>>(p);
-            else k_sweep_batch<8, 4, 0><<<grid, BLOCK, lds, h->stream>>>(p);
-        } else {
-            switch (cpg) {
-            case 2: k_sweep_batch<2, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 4: k_sweep_batch<4, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            case 8: k_sweep_batch<8, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            default: k_sweep_batch<16, 2, 0><<<grid, BLOCK, lds, h->stream>>>(p); break;
-            }
+    // the build of the kernel this sweep runs
+    void (*kern)(SweepParams) = nullptr;
+    if (mg) {
+        kern = k_sweep_batch<8, 2, 1>;
+    } else if (tier == 4) {
+        kern = (cpg == 4) ? k_sweep_batch<4, 4, 0> : k_sweep_batch<8, 4, 0>;
+    } else {
+        switch (cpg) {
+        case 2: kern = k_sweep_batch<2, 2, 0>; break;
+        case 4: kern = k_sweep_batch<4, 2, 0>; break;
+        case 8: kern = k_sweep_batch<8, 2, 0>; break;
+        default: kern = k_sweep_batch<16, 2, 0>; break;
         }
-    };
+    }
+    // the active workgroups of a launch must be co-resident (a second round of workgroups would double the streaming
+    // phase): how many fit depends on the build's registers and on this launch's LDS size (K, batch capacity, rows)
+    {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds));
+        if (per_cu < 1) return fail("hgibbs_sweep: the sweep kernel does not fit a compute unit with %zu bytes of LDS", lds);
+        p.resident = (uint32_t)per_cu * (uint32_t)h->num_cu;
+        if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep build: tier %d mg %d cpg %u, LDS %zu B, %d workgroups per CU, %u resident\n", tier, (int)mg, cpg, lds, per_cu, p.resident);
+    }
+    // the Gram partials are 16-bit fields per lane (64 per tile at most): a launch uses at least
+    // min(slices, resident / groups) slices, so a lane sees at most ntg / that many tiles -- refuse the chain of
+    // segments where that could overflow
+    {
+        const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(S, p.resident / std::max<uint32_t>(1u, ngroups)));
+        if ((ntg + s_min - 1) / s_min > 1000u) p.gram = 0;
+    }
+    auto launch_one = [&]() { kern<<<grid, BLOCK, lds, h->stream>>>(p); };
     // launch-bound inner loop: the launches of one sweep are identical (all state travels through the
     // descriptor), so GRAPH_N of them are captured once per sweep into a graph and replayed
     constexpr int GRAPH_N = 64;

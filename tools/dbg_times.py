@@ -18,7 +18,9 @@ dev.set_option("batch", batch); dev.set_option("cols_per_group", cpg); dev.set_o
 if slices: dev.set_option("slices", slices)
 if ext >= 0: dev.set_option("ext_limit", ext)
 if max_seg: dev.set_option("max_seg", max_seg)
-dev.synth_bed(N, M, seed=42)
+for kv in filter(None, os.environ.get("DBG_OPTS", "").split(",")):  # library options, "name=value,..."
+    dev.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+dev.synth_bed(N, M, seed=42, missing_rate=float(os.environ.get("DBG_MISSING", "0")))
 y = bench.make_phenotype_on_device(dev, N, M, (0, N), seed=43)
 ch = capi.Chain(dev, y, mS=np.array(mS))
 L = capi.lib(); L.hgibbs_debug_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
