@@ -60,12 +60,11 @@ struct SweepShared {
     double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns (+ sum of eps)
     double* tot;       // NROW*bcap + 1 reduced sums
     double* thr;       // [bcap][K-1]
-    double* logl;      // [bcap][K]
+    double* numf;      // [bcap] full numerator of a column once its posterior is evaluated (dot, Gram corrections, old effect's term)
     double* bold;      // [bcap]
     double* mave;
     double* mstd;
-    double* dp;        // [bcap] x_j'eps as reduced from the dots; once a column's posterior is evaluated, its full numerator
-                       // (Gram corrections and the old effect's term included): mu_k = dp / denom_k is recomputed by the drawing lane
+    double* dp;        // [bcap] x_j'eps as reduced from the dots (before corrections)
     int32_t* marker;
     int32_t* grp;
     uint32_t* flags;   // see F_* below
@@ -92,7 +91,7 @@ __host__ __device__ inline size_t sweep_lds_tail_bytes(uint32_t bcap, int K, int
 {
     size_t n = 0;
     n += (size_t)(nr * bcap + 1) * 8;                                                       // tot
-    n += (size_t)bcap * (K - 1) * 8 + (size_t)bcap * K * 8 + (size_t)bcap * 8;                // thr, logl, dp
+    n += (size_t)bcap * (K - 1) * 8 + (size_t)2 * bcap * 8;                                    // thr, dp, numf
     return (n + 15) & ~(size_t)15;
 }
 
@@ -148,7 +147,7 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.estage = q; // union starts here
     sh.tot = reinterpret_cast<double*>(q); q += (size_t)(nr * bcap + 1) * 8;
     sh.thr = reinterpret_cast<double*>(q); q += (size_t)bcap * (K - 1) * 8;
-    sh.logl = reinterpret_cast<double*>(q); q += (size_t)bcap * K * 8;
+    sh.numf = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.dp = reinterpret_cast<double*>(q); q += (size_t)bcap * 8;
     sh.bcap = bcap;
     return sh;
@@ -219,6 +218,75 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
     return best;
 }
 
+// Posterior of the batch columns [lo, hi) of segment `seg` (a5: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921), one
+// thread per (column j, step kk of the component walk): numerator of the column (dot, Gram corrections for the earlier
+// pivots' updates in order, old effect's term), log-likelihoods of all components in registers, then
+//     thr[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)   (:1883-1921).
+// The K - 1 threads of a column repeat its numerator and divisions (bit-identical): no LDS round trip and no barrier
+// between log-likelihoods and thresholds, and the divisions / exponentials of one thread are independent instruction
+// streams (KT is the unrolled component count; lanes beyond K compute on neutral operands).
+template <int KT, int MG, int NR>
+__device__ __forceinline__ void posterior_items(const SweepParams& p, const SweepShared& sh, uint32_t lo, uint32_t hi, int seg)
+{
+    const int K = p.K;
+    const bool lds_tab = p.GK <= HT_LDS;
+    for (uint32_t it = threadIdx.x; it < (hi - lo) * (uint32_t)(K - 1); it += BLOCK) {
+        const uint32_t j = lo + it / (uint32_t)(K - 1);
+        const int kk = (int)(it % (uint32_t)(K - 1));
+        if (!(sh.ada[j] & 1)) continue;
+        const int grp = sh.grp[j];
+        const double mave = sh.mave[j], mstd = sh.mstd[j];
+        double num = sh.dp[j];
+        for (int q = 0; q < seg; ++q) {
+            double xx;
+            if constexpr (MG) {
+                // missing calls in either column: x_j'x_p = mstd_j mstd_p (A - m_p B - m_j C + m_j m_p D) with the integer sums
+                // A = sum gw_j gw_p, B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p (gw = genotype * non-missing)
+                const double* r = sh.tot + NR * j + NSUM + 4 * q;
+                const double mp = sh.ev[3 * q + 1];
+                xx = mstd * sh.ev[3 * q + 2] * (((r[0] - mp * r[1]) - mave * r[2]) + (mave * mp) * r[3]);
+            } else {
+                const double A = sh.tot[NR * j + NSUM + q];
+                xx = mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mave * sh.ev[3 * q + 1]));
+            }
+            num += sh.ev[3 * q] * xx;
+        }
+        num += sh.bold[j] * p.n_minus_1;
+        if (kk == 0) sh.numf[j] = num; // mu_k = numf / denom_k is recomputed by the drawing lane
+        double L[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const bool on = k < K;
+            const int t = grp * K + (on ? k : 0);
+            const double lpi = lds_tab ? sh.htab[HT_LDS + t] : p.logpi[t];
+            if (k == 0) {
+                L[k] = lpi;
+            } else {
+                const double den = lds_tab ? sh.htab[t] : p.denom[t];
+                const double hlg = lds_tab ? sh.htab[2 * HT_LDS + t] : p.hlog[t];
+                const double mk = num / (on ? den : 1.0);
+                L[k] = lpi - hlg + mk * num * p.i_2sigE;
+            }
+        }
+        double base = L[0];
+#pragma unroll
+        for (int k = 1; k < KT - 1; ++k) base = (kk == k) ? L[k] : base;
+        bool big = false;
+        double e[KT];
+#pragma unroll
+        for (int l = 0; l < KT; ++l) {
+            const double d = L[l] - base;
+            if (l < K && l >= (kk ? kk : 1) && fabs(d) > 700.0) big = true;
+            e[l] = exp(l < K ? d : 0.0);
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < KT; ++l)
+            if (l < K) sum += e[l];
+        sh.thr[j * (K - 1) + kk] = big ? 0.0 : 1.0 / sum;
+    }
+}
+
 // Posterior + draw + bookkeeping for the markers of this batch, given the reduced
 // sums in sh.tot: rows [NROW*j ...] = (s1, s2, A_0, A_1, A_2) of batch column j, last
 // row = sum of eps.  The batch is a chain of up to MAX_SEG segments [nbs[s-1], nbs[s]);
@@ -269,6 +337,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         sh.flags[F_ERR] = 0;
     }
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[24] = wall_clock64(); // generator block + dots staged
 
     // pending updates handed to the next launch: kept in LDS by thread 0 (sh.pvl is free again: the
     // streaming loop is over), markers in sh.pmk
@@ -281,66 +350,12 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         const uint32_t lo = seg ? nbs[seg - 1] : 0u, hi = nbs[seg];
         if (lo >= hi) break; // uniform
 
-        // ---- posterior of [lo, hi), one thread per batch column -----------------
-        if ((uint32_t)tid >= lo && (uint32_t)tid < hi && mm.ada) {
-            double num = sh.dp[tid];
-            for (int q = 0; q < seg; ++q) { // Gram corrections for the earlier pivots' updates, in order
-                double xx;
-                if constexpr (MG) {
-                    // missing calls in either column: x_j'x_p = mstd_j mstd_p (A - m_p B - m_j C + m_j m_p D) with the integer sums
-                    // A = sum gw_j gw_p, B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p (gw = genotype * non-missing)
-                    const double* r = sh.tot + NR * tid + NSUM + 4 * q;
-                    const double mp = sh.ev[3 * q + 1];
-                    xx = mm.mstd * sh.ev[3 * q + 2] * (((r[0] - mp * r[1]) - mm.mave * r[2]) + (mm.mave * mp) * r[3]);
-                } else {
-                    const double A = sh.tot[NR * tid + NSUM + q];
-                    xx = mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1]));
-                }
-                num += sh.ev[3 * q] * xx;
-            }
-            num += mm.bold * p.n_minus_1;
-            double den[MAX_K], lpi[MAX_K], hlg[MAX_K];
-            if (p.GK <= HT_LDS) {
-                for (int k = 0; k < K; ++k) {
-                    den[k] = sh.htab[mm.grp * K + k];
-                    lpi[k] = sh.htab[HT_LDS + mm.grp * K + k];
-                    hlg[k] = sh.htab[2 * HT_LDS + mm.grp * K + k];
-                }
-            } else {
-                for (int k = 0; k < K; ++k) {
-                    den[k] = p.denom[(size_t)mm.grp * K + k];
-                    lpi[k] = p.logpi[(size_t)mm.grp * K + k];
-                    hlg[k] = p.hlog[(size_t)mm.grp * K + k];
-                }
-            }
-            sh.logl[tid * K] = lpi[0];
-            sh.dp[tid] = num; // each column is evaluated once (in its own segment): the slot is free for the drawing lane
-            for (int k = 1; k < K; ++k) {
-                double mk = num / den[k];
-                sh.logl[tid * K + k] = lpi[k] - hlg[k] + mk * num * p.i_2sigE;
-            }
-        }
-        __syncthreads();
-        // increments of the component walk (:1883-1921), one thread per (marker, component):
-        // q[j][kk] = 0 if any |logL_l - logL_kk| > 700 (l >= max(kk,1)) else 1 / sum_l exp(logL_l - logL_kk)
-        for (uint32_t it = tid; it < (hi - lo) * (uint32_t)(K - 1); it += BLOCK) {
-            const uint32_t j = lo + it / (uint32_t)(K - 1), kk = it % (uint32_t)(K - 1);
-            if (!(sh.ada[j] & 1)) continue;
-            const double* L = sh.logl + j * K;
-            const double base = L[kk];
-            bool big = false;
-            for (int l = (kk ? (int)kk : 1); l < K; ++l)
-                if (fabs(L[l] - base) > 700.0) big = true;
-            double q = 0.0;
-            if (!big) {
-                double sum = 0.0;
-                for (int l = 0; l < K; ++l) sum += exp(L[l] - base);
-                q = 1.0 / sum;
-            }
-            sh.thr[j * (K - 1) + kk] = q;
-        }
+        // ---- posterior of [lo, hi): one thread per (column, walk step kk) ------------
+        if (K <= 4) posterior_items<4, MG, NR>(p, sh, lo, hi, seg);
+        else posterior_items<MAX_K, MG, NR>(p, sh, lo, hi, seg);
         __syncthreads();
         if (p.dbg && tid == 0 && seg == 0) p.dbg[3] = wall_clock64();
+        if (p.dbg && tid == 0 && seg < 2) p.dbg[26 + 4 * seg] = wall_clock64(); // thresholds
 
         // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
         if (tid < WAVE) {
@@ -385,7 +400,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                     ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
                     const double sd = (p.GK <= HT_LDS) ? sh.htab[3 * HT_LDS + grp * K + k] : p.sdk[(size_t)grp * K + k];
                     const double den = (p.GK <= HT_LDS) ? sh.htab[grp * K + k] : p.denom[(size_t)grp * K + k];
-                    bnew = norm_rng_sd(g, zt, sh.dp[j] / den, sd); // the same division the posterior made
+                    bnew = norm_rng_sd(g, zt, sh.numf[j] / den, sd); // the same division the posterior made
                     consumed = g.pos - (pos + jeff + 1u);
                     gerr = g.err;
                 }
@@ -431,6 +446,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             }
         }
         __syncthreads();
+        if (p.dbg && tid == 0 && seg < 2) p.dbg[27 + 4 * seg] = wall_clock64(); // walk
 
         // an event: its update is pending for the next launch
         const bool stopped = sh.flags[F_STOP] != 0;
@@ -456,6 +472,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     // ---- hand the state to the next launch ---------------------------------------
     const uint32_t naccept = sh.flags[F_NACC];
     const uint32_t pos = sh.flags[F_POS];
+    if (p.dbg && tid == 0) p.dbg[23] = wall_clock64(); // segments done
     // ---- plan of the next launch (positions relative to the NEW cursor), by wave 0 ------------
     // segment 0 = up to and including the first predicted event (its pivot); every further
     // segment = up to and including the next predicted event, as long as the previous pivot's
@@ -538,6 +555,18 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
             p.dbg[12] += naccept;
             p.dbg[15] += 1;
+            // finer stages of the draw phase: [36] staging, [38] seg 0 posterior (numerators + thresholds), [39] seg 0 walk,
+            // [41], [42] the same for segment 1 (when it ran), [43] plan + descriptor, [44] launches with a second segment
+            p.dbg[36] += p.dbg[24] - p.dbg[2];
+            p.dbg[38] += p.dbg[26] - p.dbg[24];
+            p.dbg[39] += p.dbg[27] - p.dbg[26];
+            if (p.dbg[30] > p.dbg[27]) {
+                p.dbg[41] += p.dbg[30] - p.dbg[27];
+                p.dbg[42] += p.dbg[31] - p.dbg[30];
+                p.dbg[44] += 1;
+            }
+            p.dbg[43] += p.dbg[4] - p.dbg[23];
+            p.dbg[30] = 0;
         }
     }
     __syncthreads();

@@ -527,8 +527,8 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
     HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->dbg, 24 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->dbg, 0, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->dbg, 48 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
     *out = h;
     return 0;
@@ -1069,8 +1069,8 @@ int hgibbs_debug_times(hgibbs_t h, uint64_t* out8)
 {
     if (!h || !out8) return fail("null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy(out8, h->dbg, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(h->dbg, 0, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(out8, h->dbg, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
     return 0;
 }
 

@@ -26,7 +26,7 @@ ch = capi.Chain(dev, y, mS=np.array(mS))
 L = capi.lib(); L.hgibbs_debug_times.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 for it in range(iters):
     ch.iterate()
-    t = (C.c_uint64 * 24)(); L.hgibbs_debug_times(dev.h, t)
+    t = (C.c_uint64 * 48)(); L.hgibbs_debug_times(dev.h, t)
     t = [x for x in t]
     st = dev.sweep_stats()
     print(cfg, "it", it, "kern_us %.1f" % (st["kernel_ms_avg"] * 1e3), "launches", st["launches"],
@@ -34,3 +34,7 @@ for it in range(iters):
           "avg stages_us: main+ticket %.2f reduce %.2f posterior %.2f walk %.2f" % tuple(t[8 + i] / 100.0 / max(1, t[15]) for i in range(4)),
           "| last arriver: skew %.2f loop %.2f reduce+drain %.2f ticket %.2f" % tuple(t[i] / 100.0 / max(1, t[15]) for i in (17, 13, 14, 16)),
           "sweep_ms %.1f" % st["device_ms"])
+    n, n2 = max(1, t[15]), max(1, t[44])
+    print("   draw phase us: stage %.2f | seg0 num %.2f thr %.2f walk %.2f | seg1 (%.0f%% of launches) num %.2f thr %.2f walk %.2f | plan+desc %.2f" % (
+        t[36] / 100.0 / n, t[37] / 100.0 / n, t[38] / 100.0 / n, t[39] / 100.0 / n, 100.0 * t[44] / n, t[40] / 100.0 / n2, t[41] / 100.0 / n2,
+        t[42] / 100.0 / n2, t[43] / 100.0 / n))
