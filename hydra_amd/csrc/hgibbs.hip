@@ -1210,9 +1210,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     // data with missing calls: the two-segment build that carries the four Gram terms (A, B, C, D) takes such columns
     // through the extension; the four-segment build would stop its chain at the first of them
     // (that costs three more popcount sums per extension column and word, and a column with missing calls needs its own
-    // s2 pass anyway: measured +10 % at N = 100 K whatever the share of such columns, -12 % at N = 500 K when every column
-    // has missing calls, where the streaming loop dominates the launch)
-    const bool mg_wanted = h->gram_missing > 0 || (h->gram_missing < 0 && (h->missing_col_frac <= 0.25 || h->n_local <= 250000u));
+    // s2 pass anyway: measured +10 % at N = 100 K whatever the share of such columns, +2 % at N = 500 K when every column
+    // has missing calls -- the worst case, where the streaming loop dominates the launch)
+    const bool mg_wanted = h->gram_missing != 0;
     const bool mg = mg_wanted && h->gram && h->any_missing && cpg == 8 && (h->max_seg == 0 || h->max_seg == 2);
     const int tier = (!mg && p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
