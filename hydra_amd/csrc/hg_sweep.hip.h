@@ -979,10 +979,19 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         p.dbg[7] = t_drain;
     }
     {
+        // all rows of this thread in flight at once
+        constexpr int NRT = (NR * MAX_BATCH + BLOCK) / BLOCK;
         const uint32_t nrows = NR * nb + 1;
-        for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
-            const bool last = rr == NR * nb;
-            sh.tot[last ? NR * sh.bcap : rr] = __hip_atomic_load(p.totals + (last ? NR * MAX_BATCH : rr), HG_RLX_AGENT);
+        double v[NRT];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const uint32_t rr = (uint32_t)tid + (uint32_t)i * BLOCK;
+            v[i] = (rr < nrows) ? __hip_atomic_load(p.totals + ((rr == NR * nb) ? NR * MAX_BATCH : rr), HG_RLX_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const uint32_t rr = (uint32_t)tid + (uint32_t)i * BLOCK;
+            if (rr < nrows) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = v[i];
         }
     }
     if (tid == 0) {
