@@ -129,7 +129,8 @@ struct hgibbs_ctx {
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
     uint32_t ext_limit = 256;
     uint32_t max_seg = 0; // segments (predicted events) one launch chains through; 0 = auto: 4 (the wider kernel tier) for shards of up to
-                          // 100k individuals, where a launch is dominated by its fixed cost, else 2 (config 4: 2.84 vs 2.31 M markers/s)
+                          // 300k individuals (400k when every launch also pays a cross-GPU exchange), where fewer, longer launches win
+                          // (N = 200k: 4.77 vs 4.61 M markers/s, 250k: 3.75 vs 3.59 M, 350k: equal, 500k: 3.05 vs 3.11 M), else 2
     bool gram = true; // Gram-corrected continuation past the first predicted event
     bool use_graph = false; // replay the sweep's launches from a captured graph
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
@@ -1204,7 +1205,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
     p.ext_limit = h->ext_limit;
-    p.max_seg = h->max_seg ? std::min<uint32_t>(h->max_seg, MAX_SEG) : ((h->n_local <= (h->nranks > 1 ? 150000u : 100000u)) ? 4u : 2u);
+    p.max_seg = h->max_seg ? std::min<uint32_t>(h->max_seg, MAX_SEG) : ((h->n_local <= (h->nranks > 1 ? 400000u : 300000u)) ? 4u : 2u);
     // two builds of the kernel: tier 2 (one Gram term, two pending updates: lean registers, 3 workgroups per CU) and
     // tier 4 (three Gram terms, four pending updates; cols_per_group 4 or 8 only)
     // data with missing calls: the two-segment build that carries the four Gram terms (A, B, C, D) takes such columns
