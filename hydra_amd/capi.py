@@ -37,7 +37,7 @@ class RngState(C.Structure):
 
 class SweepStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("device_ms", C.c_double),
-                ("kernel_ms_avg", C.c_double)]
+                ("kernel_ms_avg", C.c_double), ("carried_columns", C.c_uint64)]
 
 
 class RestartState(C.Structure):
@@ -369,7 +369,7 @@ class Device:
         s = SweepStats()
         check(self.L.hgibbs_last_sweep_stats(self.h, C.byref(s)))
         return {"launches": s.launches, "nnz_updates": s.nnz_updates, "device_ms": s.device_ms,
-                "kernel_ms_avg": s.kernel_ms_avg}
+                "kernel_ms_avg": s.kernel_ms_avg, "carried_columns": s.carried_columns}
 
 
 class Chain:

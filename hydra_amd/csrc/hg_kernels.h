@@ -53,8 +53,10 @@ constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
 constexpr int MAX_SEG = 4;               // segments per launch: each ends on a predicted event (its pivot) and hands one pending update on
-constexpr int NROW = NSUM + 4;           // most rows per batch column: s1, s2 and either one Gram term per earlier pivot (MAX_SEG - 1) or, in the
-                                         // two-segment build that carries missing calls through the extension, the four terms A, B, C, D
+constexpr int NROW = NSUM + 4;           // most rows per batch column: s1, s2 and either one Gram term per earlier pivot (MAX_SEG - 1) plus the carry
+                                         // term, or, in the two-segment build that takes missing calls through the extension, the four terms A, B, C, D
+// rows per batch column of a kernel build: s1, s2, then the Gram terms: one per earlier pivot and the carry term, or A, B, C, D
+__host__ __device__ constexpr int sweep_rows(int seg, int mg) { return NSUM + (seg - 1) * (mg ? 4 : 1) + (mg ? 0 : 1); }
 constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // partial rows per slice (padded)
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
@@ -73,6 +75,13 @@ struct SweepDesc {
     uint64_t launches;      // launches that did work
     uint64_t accepted_sum;  // total accepted markers (== cursor at the end)
     uint64_t seq;           // batches since the handle was created (epoch of the cross-GPU exchange)
+    // carried dots: the first carry_n columns of the next batch were already streamed by this launch (they lay behind the
+    // event that ended it); their dots (corrected for every update but the last pending one) are in SweepParams::carry, and
+    // the next launch only takes their integer Gram term with that last pending column
+    uint32_t carry_n;
+    uint32_t pad_;
+    double carry_ev[3];     // (dbeta, mave, mstd) of the last pending event
+    uint64_t carried_sum;   // columns carried so far (statistics)
 };
 
 // In-launch cross-GPU exchange (xGMI peer mailboxes, IPC-mapped).  Rank r's
@@ -123,6 +132,8 @@ struct SweepParams {
     ZigTables zig;
     // hand-off
     SweepDesc* desc;
+    double* carry;         // [MAX_BATCH] dots of the carried columns (written by the draw phase, read by the next one)
+    uint32_t carry_on;     // 1: launches may hand dots of already streamed columns to the next one
     double* partials;      // [S_CAP][ROWS_CAP], written sc1
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals

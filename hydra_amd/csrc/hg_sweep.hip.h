@@ -29,7 +29,7 @@ struct LdsGen {
 // The few descriptor fields the streaming workgroups need (the whole SweepDesc in scalar
 // registers would crowd out the loop's pointers).
 struct DescHead {
-    uint32_t cursor, cur, rng_idx, error;
+    uint32_t cursor, cur, rng_idx, error, carry_n;
     unsigned long long seq;
     int32_t pend_marker[MAX_SEG];
     uint32_t seg_end[MAX_SEG];
@@ -43,6 +43,7 @@ __device__ __forceinline__ DescHead load_desc_head(const SweepDesc* g)
     d.rng_idx = g->rng_idx;
     d.error = g->error;
     d.seq = g->seq;
+    d.carry_n = g->carry_n;
 #pragma unroll
     for (int q = 0; q < MAX_SEG; ++q) {
         d.pend_marker[q] = g->pend_marker[q];
@@ -303,12 +304,15 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                                                  const SweepShared& sh)
 {
     const int tid = threadIdx.x;
-    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1); // rows per batch column at this tier
+    constexpr int NR = sweep_rows(SEG, MG); // rows per batch column at this tier
     const int K = p.K;
     const uint32_t nb = nbs[SEG - 1];
     const uint32_t idx0 = d.rng_idx;
     const bool need_next = idx0 + MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
     if (need_next) mt_next_block(sh.mt, tid);
+    constexpr bool CARRY = !MG;
+    const bool carry_on = CARRY && p.carry_on && p.gram;
+    const uint32_t ncarry = (carry_on && d.pend_marker[0] >= 0) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
 
     // per-column state -> LDS, dot products from the reduced rows
     struct {
@@ -330,6 +334,14 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         const double s1 = sh.tot[NR * tid];
         const double s2 = mm.miss ? sh.tot[NR * tid + 1] : sh.tot[NR * sh.bcap];
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
+        if constexpr (CARRY) {
+            // a carried column: the dot the previous launch handed on (corrected for every update but the last pending one)
+            // plus that event's dbeta * x_j'x_f, from the integer Gram term this launch took instead of the dot
+            if ((uint32_t)tid < ncarry) {
+                const double A = sh.tot[NR * tid + NR - 1];
+                sh.dp[tid] = p.carry[tid] + p.desc->carry_ev[0] * (mm.mstd * p.desc->carry_ev[2] * (A - p.n_total * (mm.mave * p.desc->carry_ev[1])));
+            }
+        }
     }
     if (tid == 0) {
         sh.flags[F_POS] = idx0;
@@ -345,6 +357,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     if (tid < 3 * MAX_SEG) sh.pvl[tid] = 0.0;
     int npend = 0;
     unsigned long long nnz_add = 0;
+    int stop_seg = -1; // segment whose walk ended on an event with a non-zero update (the last pending one)
 
     for (int seg = 0; seg < SEG; ++seg) {
         const uint32_t lo = seg ? nbs[seg - 1] : 0u, hi = nbs[seg];
@@ -461,6 +474,9 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                 }
                 ++npend;
                 ++nnz_add;
+                stop_seg = seg;
+            } else {
+                stop_seg = -1;
             }
         }
         // go on into the next segment only if this one ran to its end and ended ON its last column
@@ -472,6 +488,28 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     // ---- hand the state to the next launch ---------------------------------------
     const uint32_t naccept = sh.flags[F_NACC];
     const uint32_t pos = sh.flags[F_POS];
+    // Carried dots.  The walk ended on an event at batch position fpos with columns left behind it: their dots are
+    // stale only by that event's update (and, for later segments, by the earlier pivots' updates, for which the Gram
+    // terms are here).  Hand them on corrected for the pivots; the next launch takes the Gram term with the event's
+    // column instead of streaming them again.  Columns with missing calls (or such an event column) end the carry.
+    uint32_t carry_next = 0u;
+    if constexpr (CARRY) {
+        const uint32_t fpos = sh.flags[F_FPOS];
+        const bool can = carry_on && stop_seg >= 0 && sh.flags[F_STOP] != 0 && fpos + 1u < nb && !(sh.ada[fpos] & 2); // uniform
+        if (can) {
+            const uint32_t bad = ((uint32_t)tid > fpos && (uint32_t)tid < nb && mm.miss) ? (uint32_t)tid : nb;
+            const uint32_t first_bad = block_min_u32(sh, bad, tid);
+            carry_next = first_bad - (fpos + 1u);
+            if ((uint32_t)tid > fpos && (uint32_t)tid < first_bad) {
+                double v = sh.dp[tid];
+                for (int q = 0; q < stop_seg; ++q) { // the pivots already walked past, in order (same terms as the posterior's)
+                    const double A = sh.tot[NR * tid + NSUM + q];
+                    v += sh.ev[3 * q] * (mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1])));
+                }
+                p.carry[(uint32_t)tid - (fpos + 1u)] = v;
+            }
+        }
+    }
     if (p.dbg && tid == 0) p.dbg[23] = wall_clock64(); // segments done
     // ---- plan of the next launch (positions relative to the NEW cursor), by wave 0 ------------
     // segment 0 = up to and including the first predicted event (its pivot); every further
@@ -545,6 +583,11 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         n.accepted_sum += naccept;
         if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
+        n.carry_n = carry_next;
+        if (carry_next) {
+            for (int c = 0; c < 3; ++c) n.carry_ev[c] = sh.ev[3 * stop_seg + c];
+            n.carried_sum += carry_next;
+        }
         *p.desc = n;
         if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
             p.dbg[4] = wall_clock64();
@@ -678,7 +721,7 @@ template <int CPG, int SEG, int MG>
 __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
     static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
-    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1); // rows per batch column: s1, s2 and the Gram terms
+    constexpr int NR = sweep_rows(SEG, MG); // rows per batch column: s1, s2 and the Gram terms
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
@@ -700,6 +743,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     // slices actually used: keep the active workgroups co-resident (3 per CU at this register
     // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
     const uint32_t RES = p.resident; // co-resident workgroups of this build at this launch's LDS size (occupancy query on the host)
+    // Carried columns (the first ncarry of the batch: streamed by the previous launch, see SweepDesc::carry_n) skip the
+    // dot product and only take one integer Gram term.  Slices stay uniform: the compute units' VALUs are shared by the
+    // co-resident workgroups, so the cheap carried groups simply leave issue slots to the fresh ones (giving them fewer
+    // slices instead was measured: no difference).
+    constexpr bool CARRY = !MG;
+    const uint32_t ncarry = (CARRY && p.carry_on && p.gram && pend) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
     const uint32_t S = (RES / nactive) < p.slices_max ? ((RES / nactive) ? RES / nactive : 1u) : p.slices_max;
     if (blockIdx.x >= S * nactive) return;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
@@ -736,6 +785,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     }
     const uint8_t* colp[CPG];
     bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
+    bool ccar[CPG];  // wave-uniform: carried column (its dot is known; only the Gram term with the last pending column is taken)
     int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
     int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
 #pragma unroll
@@ -743,6 +793,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
         const int marker = nb ? p.order[d.cursor + j] : 0;
         cmiss[c] = nb ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
+        ccar[c] = c0 + c < ncarry;
         int sg = 0;
 #pragma unroll
         for (int q = 0; q < SEG - 1; ++q) sg += (c0 + c < nb && c0 + c >= nbs[q]) ? 1 : 0;
@@ -822,11 +873,20 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 gwp[q] = nmp[q] = 0u;
                 if (q < ng) code_weights(wpiv[q], gwp[q], nmp[q]);
             }
+            uint32_t gwcar = 0u; // weights of the LAST pending column: the event the carried dots are not yet corrected for
             if (pend) { // the previous launch's event(s), in order
 #pragma unroll
                 for (int q = 0; q < SEG; ++q)
                     if (q < npend) apply_update16_lds(wp[q], sh.pvt + 16 * q, e);
                 if (first_group) store_eps16(eps_out, tile, lane, e);
+                if constexpr (CARRY) {
+                    if (ccar[0]) { // carried columns are a prefix of the batch: the group has one iff its first column is
+                        uint32_t wl = wp[0], nml;
+#pragma unroll
+                        for (int q = 1; q < SEG; ++q) wl = (q == npend - 1) ? wp[q] : wl;
+                        code_weights(wl, gwcar, nml);
+                    }
+                }
             }
             if (first_group) {
 #pragma unroll
@@ -840,8 +900,9 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             if constexpr (CPG % 4 == 0) {
 #pragma unroll
                 for (int c0g = 0; c0g < CPG; c0g += 4)
-                    fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
-                               std::make_integer_sequence<int, IPT>{});
+                    if (!(CARRY && ccar[c0g + 3])) // a block of four carried columns has nothing to add (prefix: the last one decides)
+                        fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
+                                   std::make_integer_sequence<int, IPT>{});
             } else {
 #pragma unroll
                 for (int s = 0; s < IPT; ++s) {
@@ -869,6 +930,9 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                     }
                     ag01[c] += g;
                 }
+                if constexpr (CARRY) {
+                    if (ccar[c]) ag2[c] += gram16(gw[c], gwcar) << 16;
+                }
             }
             if (tgn < ntg) {
 #pragma unroll
@@ -888,16 +952,22 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             // exact: integers far below 2^53
             const double g0 = any_gram ? wave_sum((double)(ag01[c] & 0xffffu)) : 0.0;
             const double g1 = (MG ? any_gram : ng > 1) ? wave_sum((double)(ag01[c] >> 16)) : 0.0;
-            const double g2 = MG ? (any_gram ? wave_sum((double)(ag2[c] & 0xffffu)) : 0.0) : (ng > 2 ? wave_sum((double)ag2[c]) : 0.0);
-            const double g3 = (MG && any_gram) ? wave_sum((double)(ag2[c] >> 16)) : 0.0;
+            const double g2 = (MG ? any_gram : ng > 2) ? wave_sum((double)(ag2[c] & 0xffffu)) : 0.0;
+            const double g3 = ((MG && any_gram) || (CARRY && ccar[0])) ? wave_sum((double)(ag2[c] >> 16)) : 0.0; // D, or the carry term
             if (lane == 0) {
                 double* wp_ = sh.wpart + wave * sh.wstride + NR * c;
                 wp_[0] = t1;
                 wp_[1] = t2;
                 wp_[2] = g0;
-                if constexpr (NR > 3) wp_[3] = g1;
-                if constexpr (NR > 4) wp_[4] = g2;
-                if constexpr (NR > 5) wp_[5] = g3;
+                if constexpr (MG) {
+                    wp_[3] = g1;
+                    wp_[4] = g2;
+                    wp_[5] = g3;
+                } else {
+                    if constexpr (SEG > 2) wp_[3] = g1;
+                    if constexpr (SEG > 3) wp_[4] = g2;
+                    wp_[NR - 1] = g3;
+                }
             }
         }
         if (first_group) {
@@ -1025,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
 template <int SEG, int MG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
-    constexpr int NR = NSUM + (SEG - 1) * (MG ? 4 : 1);
+    constexpr int NR = sweep_rows(SEG, MG);
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;

@@ -115,6 +115,8 @@ struct hgibbs_ctx {
     SweepDesc* desc_host = nullptr; // pinned
     double* partials = nullptr;
     double* totals = nullptr;
+    double* carry = nullptr; // MAX_BATCH dots handed from one launch to the next
+    bool carry_on = true;    // option carry
     uint32_t* ticket = nullptr; // word 0: the launch-wide ticket; words 16.. : one per column group
     double* sums = nullptr;    // 3*MAX_BATCH+1 (multi-GPU exchange buffer)
     double* scratch = nullptr; // reductions
@@ -527,6 +529,7 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_BATCH) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->carry, (size_t)MAX_BATCH * sizeof(double)));
     HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&h->dbg, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
@@ -546,7 +549,7 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -1047,6 +1050,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         h->ext_limit = (uint32_t)value;
     } else if (!std::strcmp(name, "gram")) {
         h->gram = value != 0;
+    } else if (!std::strcmp(name, "carry")) {
+        h->carry_on = value != 0;
+
     } else if (!std::strcmp(name, "p2p")) {
         h->p2p_enabled = value != 0;
     } else if (!std::strcmp(name, "force_split")) {
@@ -1200,6 +1206,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.ticket = h->ticket;
     p.gticket = h->ticket + 16;
     p.totals = h->totals;
+    p.carry = h->carry;
+    // the carry term is a 16-bit field per lane like the other Gram partials; a carried column group may run on a single slice
+    p.carry_on = (h->carry_on && h->gram && h->n_pad / BLOCK_IND <= 1000u) ? 1u : 0u;
     p.nblk_x = h->n_pad / BLOCK_IND;
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
@@ -1217,7 +1226,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const bool mg = mg_wanted && h->gram && h->any_missing && cpg == 8 && (h->max_seg == 0 || h->max_seg == 2);
     const int tier = (!mg && p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
-    const int nr = NSUM + (tier - 1) * (mg ? 4 : 1);
+    const int nr = sweep_rows(tier, mg ? 1 : 0);
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K, nr);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
@@ -1324,6 +1333,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     if (nnz_updates) *nnz_updates = h->desc_host->nnz;
     h->stats.launches = total_launches;
     h->stats.nnz_updates = h->desc_host->nnz;
+    h->stats.carried_columns = h->desc_host->carried_sum;
+    if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep: %llu launches, %llu columns carried\n", (unsigned long long)total_launches, (unsigned long long)h->desc_host->carried_sum);
     h->stats.device_ms = ms;
     h->stats.kernel_ms_avg = total_launches ? ms / (double)total_launches : 0.0;
     return 0;

@@ -152,6 +152,7 @@ typedef struct {
     uint64_t nnz_updates;
     double device_ms;
     double kernel_ms_avg; /* average duration of the dominant kernel's launches */
+    uint64_t carried_columns; /* batch columns whose dot was handed on by the previous launch instead of being streamed again */
 } hgibbs_sweep_stats;
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
 /* measured streaming ceiling of this GPU: device-to-device copy of `bytes` (choose well above the 256 MB

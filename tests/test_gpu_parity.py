@@ -245,6 +245,43 @@ def test_missing_calls_ride_through_the_extension(oracle, col_frac):
     assert launches[1] < launches[0]
 
 
+@pytest.mark.parametrize("max_seg", [2, 4])
+def test_carried_dots_match_the_streamed_ones(oracle, max_seg):
+    """Columns that lay behind the event that ended a launch are not streamed again: the next launch corrects their
+    dots by dbeta * x_j'x_event from an integer Gram term (option carry).  Same chain as with the option off (same
+    launches, components, generator; floating point to 1e-9) and as the oracle; a column with missing calls ends the carry."""
+    M, N = 1500, 9000
+    geno = synth.make_genotypes(M, N, seed=41, missing_rate=0.0)
+    rng = np.random.default_rng(3)
+    for c in rng.choice(M, size=M // 25, replace=False):
+        geno[c, rng.random(N) < 0.01] = 3
+    y, _ = synth.make_phenotype(geno, seed=42, causal_frac=0.04)
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, seed=11)
+    runs = []
+    for carry in (1, 0):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("batch", 256)
+        dev.set_option("max_seg", max_seg)
+        dev.set_option("gram_missing", 0)
+        dev.set_option("carry", carry)
+        runs.append((dev, capi.Chain(dev, y, seed=11)))
+    carried = 0
+    for it in range(6):
+        ref.iterate()
+        for dev, ch in runs:
+            ch.iterate()
+            beta, comp, acum = dev.get_beta()
+            assert np.array_equal(comp, ref.arr("components")), "it %d" % it
+            assert close(beta, ref.arr("beta")) and close(acum, ref.arr("acum")) and close(dev.get_residual(), ref.arr("eps"))
+        s1, s0 = runs[0][0].sweep_stats(), runs[1][0].sweep_stats()
+        assert s1["launches"] == s0["launches"] and s0["carried_columns"] == 0
+        assert np.array_equal(runs[0][1].state()["rng_x"], runs[1][1].state()["rng_x"])
+        carried += s1["carried_columns"]
+    assert carried > M, "the carry was hardly exercised: %d columns" % carried
+
+
 def test_graph_replay_is_the_same_chain():
     """The sweep's launches replayed from a captured HIP graph (option "graph") walk the very same chain."""
     M, N = 900, 3000
