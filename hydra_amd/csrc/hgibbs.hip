@@ -126,7 +126,7 @@ struct hgibbs_ctx {
 
     // options
     uint32_t batch = 0; // 0 = auto: 256 for shards of >= 20k individuals or several ranks, else 128
-    uint32_t cols_per_group = 8;
+    uint32_t cols_per_group = 4; // measured (N = 50k / 200k / 500k): 4 beats 8 by 10 % / 7 % / 2 % (more, lighter workgroups: four waves per SIMD)
     int chunk = 0; // launches per host check (0 = adaptive)
     uint32_t slices = 0; // gridDim.x of the sweep (0 = auto)
     uint32_t ext_limit = 256;
@@ -1223,7 +1223,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     // s2 pass anyway: measured +10 % at N = 100 K whatever the share of such columns, +2 % at N = 500 K when every column
     // has missing calls -- the worst case, where the streaming loop dominates the launch)
     const bool mg_wanted = h->gram_missing != 0;
-    const bool mg = mg_wanted && h->gram && h->any_missing && cpg == 8 && (h->max_seg == 0 || h->max_seg == 2);
+    const bool mg = mg_wanted && h->gram && h->any_missing && (cpg == 4 || cpg == 8) && (h->max_seg == 0 || h->max_seg == 2);
     const int tier = (!mg && p.max_seg > 2 && h->gram && (cpg == 4 || cpg == 8)) ? 4 : 2;
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
     const int nr = sweep_rows(tier, mg ? 1 : 0);
@@ -1248,7 +1248,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     // the build of the kernel this sweep runs
     void (*kern)(SweepParams) = nullptr;
     if (mg) {
-        kern = k_sweep_batch<8, 2, 1>;
+        kern = (cpg == 4) ? k_sweep_batch<4, 2, 1> : k_sweep_batch<8, 2, 1>;
     } else if (tier == 4) {
         kern = (cpg == 4) ? k_sweep_batch<4, 4, 0> : k_sweep_batch<8, 4, 0>;
     } else {

@@ -89,12 +89,14 @@ def test_dot_and_update_single_marker(oracle, N):
         assert np.array_equal(dev.get_residual(), eps)  # bit-exact: same constants, one add
 
 
-def _gpu_sweep_vs_oracle(oracle, M, N, G, mS, groups, batch, iters=3, missing_rate=0.02, seed=1222):
+def _gpu_sweep_vs_oracle(oracle, M, N, G, mS, groups, batch, iters=3, missing_rate=0.02, seed=1222, cpg=None):
     bed, y = make_case(M, N, seed=M + N, missing_rate=missing_rate)
     ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
     dev = capi.Device(0)
     dev.load_bed(bed, N)
     dev.set_option("batch", batch)
+    if cpg:
+        dev.set_option("cols_per_group", cpg)
     ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=seed, shuffle=1)
     for it in range(iters):
         ref.iterate()
@@ -145,11 +147,13 @@ def test_chain_vs_oracle_dense_form(oracle):
         oracle.orc_set_dot_form(0)
 
 
-def test_chain_vs_oracle_groups(oracle):
+@pytest.mark.parametrize("cpg", [2, 4, 8, 16])
+def test_chain_vs_oracle_groups(oracle, cpg):
+    """Grouped mixture (BASELINE config 3's shape), once per build of the sweep kernel (columns per workgroup)."""
     M = 400
     groups = (np.arange(M) % 2).astype(np.int32)
     mS = np.array([[0.0, 0.001, 0.01, 0.1], [0.0, 0.001, 0.01, 0.1]])
-    _gpu_sweep_vs_oracle(oracle, M=M, N=4099, G=2, mS=mS, groups=groups, batch=32, iters=5)
+    _gpu_sweep_vs_oracle(oracle, M=M, N=4099, G=2, mS=mS, groups=groups, batch=32, iters=5, cpg=cpg)
 
 
 def test_chain_vs_oracle_long(oracle):
@@ -212,8 +216,8 @@ def test_gram_extension_matches_oracle_and_plain_path(oracle, batch):
         assert fewer, "the extension never saved a launch: it is not being exercised"
 
 
-@pytest.mark.parametrize("col_frac", [0.2, 1.0])
-def test_missing_calls_ride_through_the_extension(oracle, col_frac):
+@pytest.mark.parametrize("col_frac,cpg", [(0.2, 4), (1.0, 4), (1.0, 8)])
+def test_missing_calls_ride_through_the_extension(oracle, col_frac, cpg):
     """Columns with missing calls inside the Gram-corrected extension (the four-term build, option gram_missing):
     same chain as the oracle and as the build that ends the extension at such columns, in fewer launches."""
     M, N = 1200, 3000
@@ -230,6 +234,7 @@ def test_missing_calls_ride_through_the_extension(oracle, col_frac):
         dev.load_bed(bed, N)
         dev.set_option("max_seg", 2)
         dev.set_option("batch", 256)
+        dev.set_option("cols_per_group", cpg)
         dev.set_option("gram_missing", mg)
         ch = capi.Chain(dev, y, seed=8)
         tot = 0
@@ -245,8 +250,8 @@ def test_missing_calls_ride_through_the_extension(oracle, col_frac):
     assert launches[1] < launches[0]
 
 
-@pytest.mark.parametrize("max_seg", [2, 4])
-def test_carried_dots_match_the_streamed_ones(oracle, max_seg):
+@pytest.mark.parametrize("max_seg,cpg", [(2, 4), (4, 4), (2, 8), (4, 8)])
+def test_carried_dots_match_the_streamed_ones(oracle, max_seg, cpg):
     """Columns that lay behind the event that ended a launch are not streamed again: the next launch corrects their
     dots by dbeta * x_j'x_event from an integer Gram term (option carry).  Same chain as with the option off (same
     launches, components, generator; floating point to 1e-9) and as the oracle; a column with missing calls ends the carry."""
@@ -264,6 +269,7 @@ def test_carried_dots_match_the_streamed_ones(oracle, max_seg):
         dev.load_bed(bed, N)
         dev.set_option("batch", 256)
         dev.set_option("max_seg", max_seg)
+        dev.set_option("cols_per_group", cpg)
         dev.set_option("gram_missing", 0)
         dev.set_option("carry", carry)
         runs.append((dev, capi.Chain(dev, y, seed=11)))
