@@ -142,8 +142,18 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
                  const double* estPi_host, const uint8_t* adaV_host, hgibbs_rng_state* rng, int32_t* cass_host,
                  uint64_t* nnz_updates);
 
-/* Tuning knobs (not part of the reference's behaviour): name/value pairs such
- * as "batch" (speculative batch width), "mode" (0 per-marker, 1 batched). */
+/* Tuning knobs of the sweep (not part of the reference's behaviour; every setting gives the same chain up to
+ * floating-point rounding, and bit-identical chains with gram = 0).  0 = automatic where noted.
+ *   batch           speculative batch width, 1..256 (0 auto)
+ *   cols_per_group  batch columns per workgroup: 2, 4 (default), 8, 16
+ *   slices          most tile-group slices per column group, 1..64 (0 auto)
+ *   gram            1 (default): continue past predicted events with Gram-corrected dots
+ *   max_seg         segments (predicted events) per launch, 1..4 (0 auto by shard size)
+ *   ext_limit       longest Gram-corrected extension in columns (default 256)
+ *   gram_missing    -1 auto / 0 / 1: take columns with missing calls through the extension (four-term build)
+ *   carry           1 (default): hand the dots of columns behind an unplanned event to the next launch
+ *   graph           1: replay the launches from a captured HIP graph
+ *   p2p, force_split, chunk, debug_timing, w_kernel_timing   transport selection and diagnostics */
 int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value);
 /* Statistics of the last sweep: launches, markers per launch, device time of
  * the sweep in ms (HIP events on the sweep's stream). */
