@@ -35,6 +35,6 @@ for it in range(iters):
           "| last arriver: skew %.2f loop %.2f reduce+drain %.2f ticket %.2f" % tuple(t[i] / 100.0 / max(1, t[15]) for i in (17, 13, 14, 16)),
           "sweep_ms %.1f" % st["device_ms"])
     n, n2 = max(1, t[15]), max(1, t[44])
-    print("   draw phase us: stage %.2f | seg0 num %.2f thr %.2f walk %.2f | seg1 (%.0f%% of launches) num %.2f thr %.2f walk %.2f | plan+desc %.2f" % (
-        t[36] / 100.0 / n, t[37] / 100.0 / n, t[38] / 100.0 / n, t[39] / 100.0 / n, 100.0 * t[44] / n, t[40] / 100.0 / n2, t[41] / 100.0 / n2,
+    print("   draw phase us: stage %.2f | seg0 posterior %.2f walk %.2f | seg1 (%.0f%% of launches) posterior %.2f walk %.2f | plan+desc %.2f" % (
+        t[36] / 100.0 / n, t[38] / 100.0 / n, t[39] / 100.0 / n, 100.0 * t[44] / n, t[41] / 100.0 / n2,
         t[42] / 100.0 / n2, t[43] / 100.0 / n))
