@@ -556,6 +556,46 @@ def test_mixture_sizes(oracle, K):
     _gpu_sweep_vs_oracle(oracle, M=150, N=700, G=1, mS=mS, groups=None, batch=64, iters=4)
 
 
+@pytest.mark.parametrize("case", range(32))
+def test_random_configurations_match_the_oracle(oracle, case):
+    """Seeded random combinations of shape (ragged N, M), mixture size, groups, share of columns with missing calls,
+    causal share, and of every tuning knob of the sweep (batch width, columns per workgroup, segments, Gram / carry /
+    missing-call builds): four iterations against the oracle each."""
+    rng = np.random.default_rng(1000 + case)
+    N = int(rng.choice([61, 700, 4097, 9000, 20011]))
+    M = int(rng.integers(40, 900))
+    K = int(rng.integers(2, 9))
+    G = int(rng.choice([1, 1, 2, 3]))
+    geno = synth.make_genotypes(M, N, seed=500 + case, missing_rate=0.0, maf_lo=0.1 if N < 1000 else 0.01)
+    for c in rng.choice(M, size=int(rng.choice([0.0, 0.1, 1.0]) * M), replace=False):
+        geno[c, rng.random(N) < 0.03] = 3
+    for c in range(M):  # no monomorphic marker: its scale is a division by zero in the reference too (src/BayesRRm.cpp:1506)
+        if len(np.unique(geno[c][geno[c] != 3])) < 2:
+            geno[c, :3] = (0, 1, 2)
+    y, _ = synth.make_phenotype(geno, seed=600 + case, causal_frac=float(rng.choice([0.01, 0.05, 0.2])))
+    bed = synth.pack_bed_columns(geno)
+    groups = None if G == 1 else rng.integers(0, G, size=M).astype(np.int32)
+    mS = np.tile(np.array([[0.0] + [10.0 ** (-(K - 1 - k)) for k in range(1, K)]]), (G, 1))
+    opts = {"batch": int(rng.choice([3, 32, 100, 256])), "cols_per_group": int(rng.choice([2, 4, 8, 16])),
+            "max_seg": int(rng.choice([0, 1, 2, 3, 4])), "gram": int(rng.choice([0, 1, 1, 1])),
+            "carry": int(rng.choice([0, 1, 1])), "gram_missing": int(rng.choice([-1, 0, 1])),
+            "ext_limit": int(rng.choice([8, 256]))}
+    ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=77 + case, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    for k, v in opts.items():
+        dev.set_option(k, v)
+    ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=77 + case, shuffle=1)
+    for it in range(4):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        what = "case %d it %d: N=%d M=%d K=%d G=%d %r" % (case, it, N, M, K, G, opts)
+        assert np.array_equal(comp, ref.arr("components")), what
+        assert close(beta, ref.arr("beta")) and close(acum, ref.arr("acum")) and close(dev.get_residual(), ref.arr("eps")), what
+        assert close(ch.state()["sigmaE"], ref.sigmaE) and ch.last_nnz() == oracle.orc_chain_last_nnz(ref.h), what
+
+
 def test_too_many_components_is_an_error():
     bed, y = make_case(10, 50, seed=1)
     dev = capi.Device(0)
