@@ -760,10 +760,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
 
-    // latency-bound loads of the draw phase, issued by EVERY workgroup before the
-    // streaming loop (any of them may turn out to be the last arriver)
-    if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
-    if (!p.sums_out) stage_rng(p, sh, tid);
     if (pend && tid < 16 * SEG) { // entry (c1 << 2 | c0) of pending update q: the addends of two neighbouring individuals
         const int q = tid >> 4;
         const double* pv = p.desc->pv[q];
@@ -840,6 +836,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             for (int q = 0; q < SEG; ++q)
                 if (q < npend) wp[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tile << 8) + voff);
         }
+        // latency-bound loads of the draw phase, issued by EVERY workgroup before the streaming loop (any of them may turn
+        // out to be the last arriver) -- but behind the first tile's loads, so that their load -> LDS round trips overlap
+        // with the column bytes' way from HBM instead of preceding it
+        if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
+        if (!p.sums_out) stage_rng(p, sh, tid);
         for (; tg < ntg; tg += S) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this tile's DMA (and column dwords) have landed
