@@ -104,11 +104,7 @@ struct SweepParams {
     double n_minus_1;      // (double)(N_global - 1)
     double n_total;        // (double)N_global
     int gram;              // 1: extend batches past the first predicted event with Gram-corrected dots
-    const double* mave;
-    const double* mstd;
-    const int32_t* groups;
     const int32_t* order;
-    const uint8_t* adaV;
     // per-marker metadata gathered into SWEEP order once per sweep (k_gather_meta)
     const double* s_mave;
     const double* s_mstd;
@@ -138,7 +134,6 @@ struct SweepParams {
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals
     uint32_t* gticket;     // [MAX_BATCH]: per column group, workgroups that have stored their partials
-    uint32_t nblk_x;
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)

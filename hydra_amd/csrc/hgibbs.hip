@@ -1178,11 +1178,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.n_minus_1 = dNm1;
     p.n_total = (double)h->n_global;
     p.gram = h->gram ? 1 : 0;
-    p.mave = h->mave;
-    p.mstd = h->mstd;
-    p.groups = h->groups;
     p.order = h->order;
-    p.adaV = h->adaV;
     p.beta = h->beta;
     p.comp = h->comp;
     p.acum = h->acum;
@@ -1209,7 +1205,6 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.carry = h->carry;
     // the carry term is a 16-bit field per lane like the other Gram partials; a carried column group may run on a single slice
     p.carry_on = (h->carry_on && h->gram && h->n_pad / BLOCK_IND <= 1000u) ? 1u : 0u;
-    p.nblk_x = h->n_pad / BLOCK_IND;
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
