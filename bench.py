@@ -449,7 +449,8 @@ def main():
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
                        "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
-                       "launches_per_iter": launches / K, "setup_s": t_setup,
+                       "launches_per_iter": launches / K, "carried_columns_per_iter": sum(s["carried_columns"] for s, _ in stats) / K,
+                       "setup_s": t_setup,
                        **({"missing_rate": args.missing} if args.missing else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (256 if (hi - lo) >= 200000 or world > 1 else 128), world),
