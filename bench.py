@@ -213,7 +213,7 @@ def cpu_baseline(dev, y, N, M, mS, groups, sample_markers, threads):
                     return {"value": r["markers_per_s"], "unit": "markers/s", "cores": thr, "kind": "port", "cpu": cpu_model(),
                             "reference_probe": reference_probe(),
                             "sample": "restated hydra AVX2 path (LUT + _mm256 dot, OpenMP over individuals, reference's update "
-                                      "bookkeeping passes), first %d of %d markers, N=%d, 1 Gibbs iteration after 1 warm-up, %s, %s"
+                                      "bookkeeping passes), first %d of %d markers, N=%d, mean of 3 Gibbs iterations after 1 warm-up, %s, %s"
                                       % (ms, M, N, lib_name, flags)}
                 print("cpu_baseline with %s failed (rc %d): %s" % (lib_name, out.returncode, out.stderr[-400:]), file=sys.stderr)
             except Exception as e:
