@@ -62,19 +62,22 @@ def _worker(rank, world, port, bed, y, N, iters, batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch", [16, 64])
-def test_two_ranks_one_gpu_p2p_exchange(batch):
+@pytest.mark.parametrize("batch,M,N,world,miss", [(16, 300, 9000, 2, 0.01), (64, 300, 9000, 2, 0.01), (256, 700, 33000, 2, 0.0),
+                                                  (256, 500, 21000, 3, 0.0)])
+def test_two_ranks_one_gpu_p2p_exchange(batch, M, N, world, miss):
+    """The larger cases run several slices per column group, the four-segment build and carried dots through the
+    sharded path (the carry term is one of the exchanged rows); three ranks give ragged shards."""
     import torch.multiprocessing as mp
     from hydra_amd import capi, synth
-    M, N, iters = 300, 9000, 3
-    geno = synth.make_genotypes(M, N, seed=61, missing_rate=0.01)
+    iters = 3
+    geno = synth.make_genotypes(M, N, seed=61, missing_rate=miss)
     y, _ = synth.make_phenotype(geno, seed=62, causal_frac=0.05)
     bed = synth.pack_bed_columns(geno)
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bed, y, N, iters, batch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, batch, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -93,12 +96,13 @@ def test_two_ranks_one_gpu_p2p_exchange(batch):
     beta, comp, _ = dev.get_beta()
     st = ch.state()
     # replicas identical
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]) and res[0][3] == r[3]
     # equal to the single-rank chain (different summation tree: tolerance on beta, exact components)
     assert np.array_equal(res[0][2], comp)
     assert np.all(np.abs(res[0][1] - beta) <= 1e-9 * np.maximum(1.0, np.abs(beta)))
     assert abs(res[0][3] - st["sigmaE"]) <= 1e-9 * st["sigmaE"]
-    eps = np.concatenate([res[0][5], res[1][5]])
+    eps = np.concatenate([r[5] for r in res])
     assert np.allclose(eps, dev.get_residual(), rtol=0, atol=1e-9)
     assert res[0][6] == ch.last_nnz()
 
@@ -168,7 +172,8 @@ def test_bayesw_two_ranks_one_gpu(with_cov):
     st = ch.state()
     tol = lambda a, b: np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-8 * np.maximum(1.0, np.abs(np.asarray(b))))
     # replicas identical, bit for bit (same all-reduced sums, same generators)
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]) and res[0][3] == r[3] and res[0][4] == res[1][4]
     # equal to the single-rank chain up to the summation tree
     assert np.array_equal(res[0][2], comp) and tol(res[0][1], beta) and tol(res[0][3], st["mu"]) and tol(res[0][4], st["alpha"])
     assert tol(res[0][5], st["sigmaG"]) and res[0][7] == ch.last_nnz()
