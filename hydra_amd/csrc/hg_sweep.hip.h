@@ -702,11 +702,28 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __syncthreads();
     if (sh.flags[F_P2PTMO]) return false;
-    for (uint32_t rr = tid; rr < nrows; rr += BLOCK) {
-        double acc = 0.0;
-        for (int r = 0; r < nr; ++r)
-            acc += __hip_atomic_load(p.p2p.data[me] + (size_t)(parity * MAX_RANKS + (uint32_t)r) * ROWS_CAP + rr, HG_RLX_SYSTEM);
-        sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc;
+    // my mailbox is uncached memory: every load is a full round trip, so all ranks' values of two rows are in flight at once;
+    // added in rank order
+    for (uint32_t rr0 = tid; rr0 < nrows; rr0 += 2 * BLOCK) {
+        double v[2][MAX_RANKS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t rr = rr0 + (uint32_t)i * BLOCK;
+#pragma unroll
+            for (int r = 0; r < MAX_RANKS; ++r)
+                v[i][r] = (rr < nrows && r < nr)
+                              ? __hip_atomic_load(p.p2p.data[me] + (size_t)(parity * MAX_RANKS + (uint32_t)r) * ROWS_CAP + rr, HG_RLX_SYSTEM)
+                              : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t rr = rr0 + (uint32_t)i * BLOCK;
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < MAX_RANKS; ++r)
+                if (r < nr) acc += v[i][r];
+            if (rr < nrows) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc;
+        }
     }
     __syncthreads();
     return true;
