@@ -734,9 +734,12 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
 // (4 wave tiles = 4096 individuals each).  Every lane keeps the sums of its
 // columns in registers across all its tiles; one wave/block reduction per
 // launch, then per-slice partial rows for the last arriver.
-template <int CPG, int SEG, int MG>
+// NOMISS: the data has no missing call in any column (known from the marker statistics): the second masked sum and its
+// reductions are compiled out (s2 is the sum of eps for every column).
+template <int CPG, int SEG, int MG, int NOMISS = 0>
 __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
+    static_assert(!(MG && NOMISS), "the missing-call Gram build is for data with missing calls");
     static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
     constexpr int NR = sweep_rows(SEG, MG); // rows per batch column: s1, s2 and the Gram terms
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     for (int c = 0; c < CPG; ++c) {
         const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
         const int marker = nb ? p.order[d.cursor + j] : 0;
-        cmiss[c] = nb ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
+        cmiss[c] = (!NOMISS && nb) ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
         ccar[c] = c0 + c < ncarry;
         int sg = 0;
 #pragma unroll
@@ -930,9 +933,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             }
 #pragma unroll
             for (int c = 0; c < CPG; ++c) {
-                if (cmiss[c]) {
+                if constexpr (!NOMISS) {
+                    if (cmiss[c]) {
 #pragma unroll
-                    for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
+                        for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
+                    }
                 }
                 if (cseg[c] > 0) {
                     uint32_t g = gram16(gw[c], gwp[0]);
@@ -966,7 +971,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         // one cross-lane reduction per launch
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
-            const double t1 = wave_sum(a1[c]), t2 = wave_sum(a2[c]);
+            const double t1 = wave_sum(a1[c]), t2 = NOMISS ? 0.0 : wave_sum(a2[c]);
             // exact: integers far below 2^53
             const double g0 = any_gram ? wave_sum((double)(ag01[c] & 0xffffu)) : 0.0;
             const double g1 = (MG ? any_gram : ng > 1) ? wave_sum((double)(ag01[c] >> 16)) : 0.0;

@@ -1245,11 +1245,11 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     if (mg) {
         kern = (cpg == 4) ? k_sweep_batch<4, 2, 1> : k_sweep_batch<8, 2, 1>;
     } else if (tier == 4) {
-        kern = (cpg == 4) ? k_sweep_batch<4, 4, 0> : k_sweep_batch<8, 4, 0>;
+        kern = (cpg == 4) ? (h->any_missing ? k_sweep_batch<4, 4, 0> : k_sweep_batch<4, 4, 0, 1>) : k_sweep_batch<8, 4, 0>;
     } else {
         switch (cpg) {
         case 2: kern = k_sweep_batch<2, 2, 0>; break;
-        case 4: kern = k_sweep_batch<4, 2, 0>; break;
+        case 4: kern = h->any_missing ? k_sweep_batch<4, 2, 0> : k_sweep_batch<4, 2, 0, 1>; break;
         case 8: kern = k_sweep_batch<8, 2, 0>; break;
         default: kern = k_sweep_batch<16, 2, 0>; break;
         }
