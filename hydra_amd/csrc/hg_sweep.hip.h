@@ -299,10 +299,11 @@ __device__ __forceinline__ void posterior_items(const SweepParams& p, const Swee
 // with A_jq = sum_i gw_j gw_q the integer Gram term accumulated by the streaming loop.
 // Runs in ONE workgroup of 256 threads.
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
-template <int SEG, int MG>
+template <int SEG, int MG, int DBG>
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const DescHead& d, const uint32_t (&nbs)[SEG],
                                                  const SweepShared& sh)
 {
+    unsigned long long* const dbgp = DBG ? p.dbg : nullptr; // stage timestamps: compiled out of the production builds
     const int tid = threadIdx.x;
     constexpr int NR = sweep_rows(SEG, MG); // rows per batch column at this tier
     const int K = p.K;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         sh.flags[F_ERR] = 0;
     }
     __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[24] = wall_clock64(); // generator block + dots staged
+    if (dbgp && tid == 0) dbgp[24] = wall_clock64(); // generator block + dots staged
 
     // pending updates handed to the next launch: kept in LDS by thread 0 (sh.pvl is free again: the
     // streaming loop is over), markers in sh.pmk
@@ -367,8 +368,8 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if (K <= 4) posterior_items<4, MG, NR>(p, sh, lo, hi, seg);
         else posterior_items<MAX_K, MG, NR>(p, sh, lo, hi, seg);
         __syncthreads();
-        if (p.dbg && tid == 0 && seg == 0) p.dbg[3] = wall_clock64();
-        if (p.dbg && tid == 0 && seg < 2) p.dbg[26 + 4 * seg] = wall_clock64(); // thresholds
+        if (dbgp && tid == 0 && seg == 0) dbgp[3] = wall_clock64();
+        if (dbgp && tid == 0 && seg < 2) dbgp[26 + 4 * seg] = wall_clock64(); // thresholds
 
         // ---- the walk: wave 0 consumes the stream in marker order, 64 at a time --
         if (tid < WAVE) {
@@ -459,7 +460,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             }
         }
         __syncthreads();
-        if (p.dbg && tid == 0 && seg < 2) p.dbg[27 + 4 * seg] = wall_clock64(); // walk
+        if (dbgp && tid == 0 && seg < 2) dbgp[27 + 4 * seg] = wall_clock64(); // walk
 
         // an event: its update is pending for the next launch
         const bool stopped = sh.flags[F_STOP] != 0;
@@ -510,7 +511,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             }
         }
     }
-    if (p.dbg && tid == 0) p.dbg[23] = wall_clock64(); // segments done
+    if (dbgp && tid == 0) dbgp[23] = wall_clock64(); // segments done
     // ---- plan of the next launch (positions relative to the NEW cursor), by wave 0 ------------
     // segment 0 = up to and including the first predicted event (its pivot); every further
     // segment = up to and including the next predicted event, as long as the previous pivot's
@@ -589,27 +590,27 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
             n.carried_sum += carry_next;
         }
         *p.desc = n;
-        if (p.dbg) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
-            p.dbg[4] = wall_clock64();
-            for (int i = 0; i < 4; ++i) p.dbg[8 + i] += p.dbg[i + 1] - p.dbg[i];
-            p.dbg[13] += p.dbg[6] - p.dbg[5]; // last arriver: entry -> loop done
-            p.dbg[14] += p.dbg[7] - p.dbg[6]; // last arriver: loop done -> drained
-            p.dbg[16] += p.dbg[1] - p.dbg[7]; // last arriver: drained -> past ticket
-            p.dbg[17] += p.dbg[5] - p.dbg[0]; // first block entry -> last arriver entry
-            p.dbg[12] += naccept;
-            p.dbg[15] += 1;
+        if (dbgp) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
+            dbgp[4] = wall_clock64();
+            for (int i = 0; i < 4; ++i) dbgp[8 + i] += dbgp[i + 1] - dbgp[i];
+            dbgp[13] += dbgp[6] - dbgp[5]; // last arriver: entry -> loop done
+            dbgp[14] += dbgp[7] - dbgp[6]; // last arriver: loop done -> drained
+            dbgp[16] += dbgp[1] - dbgp[7]; // last arriver: drained -> past ticket
+            dbgp[17] += dbgp[5] - dbgp[0]; // first block entry -> last arriver entry
+            dbgp[12] += naccept;
+            dbgp[15] += 1;
             // finer stages of the draw phase: [36] staging, [38] seg 0 posterior (numerators + thresholds), [39] seg 0 walk,
             // [41], [42] the same for segment 1 (when it ran), [43] plan + descriptor, [44] launches with a second segment
-            p.dbg[36] += p.dbg[24] - p.dbg[2];
-            p.dbg[38] += p.dbg[26] - p.dbg[24];
-            p.dbg[39] += p.dbg[27] - p.dbg[26];
-            if (p.dbg[30] > p.dbg[27]) {
-                p.dbg[41] += p.dbg[30] - p.dbg[27];
-                p.dbg[42] += p.dbg[31] - p.dbg[30];
-                p.dbg[44] += 1;
+            dbgp[36] += dbgp[24] - dbgp[2];
+            dbgp[38] += dbgp[26] - dbgp[24];
+            dbgp[39] += dbgp[27] - dbgp[26];
+            if (dbgp[30] > dbgp[27]) {
+                dbgp[41] += dbgp[30] - dbgp[27];
+                dbgp[42] += dbgp[31] - dbgp[30];
+                dbgp[44] += 1;
             }
-            p.dbg[43] += p.dbg[4] - p.dbg[23];
-            p.dbg[30] = 0;
+            dbgp[43] += dbgp[4] - dbgp[23];
+            dbgp[30] = 0;
         }
     }
     __syncthreads();
@@ -736,9 +737,11 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
 // launch, then per-slice partial rows for the last arriver.
 // NOMISS: the data has no missing call in any column (known from the marker statistics): the second masked sum and its
 // reductions are compiled out (s2 is the sum of eps for every column).
-template <int CPG, int SEG, int MG, int NOMISS = 0>
+// DBG: stage timestamps (option debug_timing); the production builds carry none of it.
+template <int CPG, int SEG, int MG, int NOMISS = 0, int DBG = 0>
 __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
+    unsigned long long* const dbgp = DBG ? p.dbg : nullptr;
     static_assert(!(MG && NOMISS), "the missing-call Gram build is for data with missing calls");
     static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
     constexpr int NR = sweep_rows(SEG, MG); // rows per batch column: s1, s2 and the Gram terms
@@ -786,8 +789,8 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         auto addend = [&](uint32_t c) { return 0.0 + ((c == 3u) ? pv[0] : ((c == 2u) ? pv[1] : ((c == 0u) ? pv[2] : 0.0))); };
         sh.pvt[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
     }
-    if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[0] = wall_clock64();
-    const unsigned long long t_entry = p.dbg ? wall_clock64() : 0ull;
+    if (dbgp && blockIdx.x == 0 && tid == 0) dbgp[0] = wall_clock64();
+    const unsigned long long t_entry = dbgp ? wall_clock64() : 0ull;
 
     unsigned long long t_loop = 0ull;
     double a1[CPG], a2[CPG], sall = 0.0;
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             }
         }
         __syncthreads(); // every wave is done with its staging tile: the union region may be reused
-        t_loop = p.dbg ? wall_clock64() : 0ull;
+        t_loop = dbgp ? wall_clock64() : 0ull;
         // one cross-lane reduction per launch
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
     __syncthreads();
-    const unsigned long long t_drain = p.dbg ? wall_clock64() : 0ull;
+    const unsigned long long t_drain = dbgp ? wall_clock64() : 0ull;
     // Two-level hand-off.  First the S workgroups of one column group: the last of them to arrive sums
     // that group's rows over the slices in fixed order -- threads 0..127 take slices 0..31 of row t,
     // threads 128..255 slices 32..63 (all 32 loads in flight; partials is [slice][row], so the loads of
@@ -1065,11 +1068,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     if (!sh.flags[F_LAST]) return;
 
     // ---- last-arriving workgroup ---------------------------------------------
-    if (p.dbg && tid == 0) {
-        p.dbg[1] = wall_clock64();
-        p.dbg[5] = t_entry;
-        p.dbg[6] = t_loop;
-        p.dbg[7] = t_drain;
+    if (dbgp && tid == 0) {
+        dbgp[1] = wall_clock64();
+        dbgp[5] = t_entry;
+        dbgp[6] = t_loop;
+        dbgp[7] = t_drain;
     }
     {
         // all rows of this thread in flight at once
@@ -1092,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         sh.flags[F_P2PTMO] = 0u;
     }
     __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[2] = wall_clock64();
+    if (dbgp && tid == 0) dbgp[2] = wall_clock64();
 
     if (p.p2p.nranks > 1 && !p.sums_out) { // multi-GPU, in-launch exchange
         if (!p2p_exchange<NR>(p, d, nb, sh)) {
@@ -1111,13 +1114,15 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         }
         return;
     }
-    sweep_draw_phase<SEG, MG>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG, DBG>(p, d, nbs, sh);
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
 template <int SEG, int MG>
 __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
 {
+    unsigned long long* const dbgp = nullptr;
+    (void)dbgp;
     constexpr int NR = sweep_rows(SEG, MG);
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
@@ -1136,7 +1141,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
     if (threadIdx.x == 0) sh.tot[NR * sh.bcap] = p.sums_out[NR * MAX_BATCH];
     __syncthreads();
-    sweep_draw_phase<SEG, MG>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG, 0>(p, d, nbs, sh);
 }
 
 } // namespace hg

@@ -1189,7 +1189,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.s_mstd = h->s_mstd;
     p.s_bold = h->s_bold;
     p.s_ga = h->s_ga;
-    p.dbg = h->debug_timing ? h->dbg : nullptr;
+    p.dbg = (h->debug_timing && h->cols_per_group == 4) ? h->dbg : nullptr;
     p.denom = h->tables;
     p.logpi = h->tables + (size_t)G * K;
     p.hlog = h->tables + (size_t)2 * G * K;
@@ -1242,14 +1242,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     uint64_t total_launches = 0;
     // the build of the kernel this sweep runs
     void (*kern)(SweepParams) = nullptr;
+    const bool nomiss = !h->any_missing;
+    const bool dbg = h->debug_timing && cpg == 4; // stage timestamps exist in the builds of the default column count only
     if (mg) {
-        kern = (cpg == 4) ? k_sweep_batch<4, 2, 1> : k_sweep_batch<8, 2, 1>;
+        kern = (cpg == 4) ? (dbg ? k_sweep_batch<4, 2, 1, 0, 1> : k_sweep_batch<4, 2, 1>) : k_sweep_batch<8, 2, 1>;
     } else if (tier == 4) {
-        kern = (cpg == 4) ? (h->any_missing ? k_sweep_batch<4, 4, 0> : k_sweep_batch<4, 4, 0, 1>) : k_sweep_batch<8, 4, 0>;
+        if (cpg == 4) kern = nomiss ? (dbg ? k_sweep_batch<4, 4, 0, 1, 1> : k_sweep_batch<4, 4, 0, 1>) : (dbg ? k_sweep_batch<4, 4, 0, 0, 1> : k_sweep_batch<4, 4, 0>);
+        else kern = k_sweep_batch<8, 4, 0>;
     } else {
         switch (cpg) {
         case 2: kern = k_sweep_batch<2, 2, 0>; break;
-        case 4: kern = h->any_missing ? k_sweep_batch<4, 2, 0> : k_sweep_batch<4, 2, 0, 1>; break;
+        case 4: kern = nomiss ? (dbg ? k_sweep_batch<4, 2, 0, 1, 1> : k_sweep_batch<4, 2, 0, 1>) : (dbg ? k_sweep_batch<4, 2, 0, 0, 1> : k_sweep_batch<4, 2, 0>); break;
         case 8: kern = k_sweep_batch<8, 2, 0>; break;
         default: kern = k_sweep_batch<16, 2, 0>; break;
         }
