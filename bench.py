@@ -55,20 +55,42 @@ def algorithmic_bytes_bw(n, M, nnz, nshift):
     return M * (col + 8 * n) + nnz * 24 * n
 
 
-def measured_traffic(N, batch, world):
-    """HBM-side bytes per k_sweep_batch launch from the committed rocprofv3 PMC
-    passes (profiles/r*_pmc_traffic.json: FETCH_SIZE doubled + WRITE_SIZE, the
-    gfx950 correction of MI355X_MICROARCH.md), when they were taken on this
-    workload; None otherwise."""
+def committed_profile(kind, N, M, world):
+    """A PMC summary committed under profiles/ (tools/profile_round.sh), newest round first, IF it was taken on this very
+    workload (same N and M, one GPU); (dict, "file: command") or (None, None).  bench.py never presents such a figure
+    without its source: the counters need rocprofv3 passes of their own and cannot be read inside this run."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc_%s.json" % kind)), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("N") == N and d.get("batch") == batch and world == 1:
-            return float(d["traffic_bytes_per_launch"])
-    return None
+        if d.get("N") == N and d.get("M") == M and world == 1:
+            return d, "%s: %s" % (os.path.relpath(f, ROOT), d.get("command", ""))
+    return None, None
+
+
+def launch_anatomy(dev, chain):
+    """One more (untimed) iteration on the build of the sweep kernel that carries stage timestamps (option
+    debug_timing): where a working launch spends its time, in microseconds, averaged over that iteration."""
+    dev.set_option("debug_timing", 1)
+    try:
+        dev.debug_times()  # clear
+        chain.iterate()
+        t = dev.debug_times()
+        st = dev.sweep_stats()
+    finally:
+        dev.set_option("debug_timing", 0)
+    n = max(1, int(t[15]))
+    us = lambda x: float(x) / 100.0 / n  # 100 MHz ticks
+    inside = us(t[8] + t[9] + t[10] + t[11])
+    period = st["kernel_ms_avg"] * 1e3
+    return {"period_us": period, "entry_and_streaming_loop_us": us(t[13]), "wave_reduction_and_drain_us": us(t[14]),
+            "hand_off_tickets_us": us(t[16]) + us(t[9]), "draw_phase_us": us(t[10] + t[11]),
+            "draw_detail_us": {"staging": us(t[36]), "seg0_posterior": us(t[38]), "seg0_walk": us(t[39]),
+                               "later_segments": us(t[41] + t[42]), "plan_and_descriptor": us(t[43])},
+            "launch_gap_and_skew_us": max(0.0, period - inside), "accepted_per_launch": float(t[12]) / n,
+            "note": "build with stage timestamps (a few % slower than the timed one); last-arriving workgroup's view"}
 
 
 def make_phenotype_on_device(dev, n_global, M, rank_rows, seed, h2=0.5, causal_frac=0.01):
@@ -327,6 +349,8 @@ def main():
     ap.add_argument("--graph", type=int, default=-1, help="replay the sweep's launches from a HIP graph (1) or launch them one by one (0)")
     ap.add_argument("--max-seg", type=int, default=0, help="segments (predicted events) one launch may chain through (0 = library default)")
     ap.add_argument("--missing", type=float, default=0.0)
+    ap.add_argument("--causal-frac", type=float, default=0.01, help="share of markers with a simulated effect (SURVEY.md 8d: 1 %%)")
+    ap.add_argument("--no-anatomy", action="store_true", help="skip the extra untimed iteration with stage timestamps")
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
                     help="per-batch cross-GPU exchange: in-launch peer mailboxes, RCCL all-reduce, or self-checked choice")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (hgibbs_set_option), repeatable: option scans")
@@ -387,7 +411,7 @@ def main():
 
     t_setup = time.perf_counter()
     dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)
-    y_loc = make_phenotype_on_device(dev, N, M, (lo, hi), seed=43)
+    y_loc = make_phenotype_on_device(dev, N, M, (lo, hi), seed=43, causal_frac=args.causal_frac)
     if world > 1:
         parts = [None] * world
         dist.all_gather_object(parts, y_loc)
@@ -426,11 +450,56 @@ def main():
         value = M * K / dt
         n_local = hi - lo
         sweep_ms = sum(s["device_ms"] for s, _ in stats)
-        launches = sum(s["launches"] for s, _ in stats)
+        enqueued = sum(s["launches"] for s, _ in stats)
+        launches = sum(s["working_launches"] for s, _ in stats)  # launches that accepted markers or applied an update
+        accepted = sum(s["accepted_markers"] for s, _ in stats)
+        streamed = sum(s["streamed_columns"] for s, _ in stats)
+        carried = sum(s["carried_columns"] for s, _ in stats)
         nnz = sum(n for _, n in stats)
         bytes_alg = sum(algorithmic_bytes(n_local, M, n) for _, n in stats)
+        # HIP events on the sweep's stream around each sweep / working launches: the average period of a working launch
+        # (back-to-back launches: duration + the gap between dependent launches; rocprofv3's average duration agrees, profiles/)
         kernel_ms_avg = sweep_ms / max(1, launches)
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
+        traffic, traffic_src = committed_profile("traffic", N, M, world)
+        valu, valu_src = committed_profile("valu", N, M, world)
+        anatomy = None
+        if not args.no_anatomy and world == 1:
+            try:
+                anatomy = launch_anatomy(dev, chain)
+            except Exception as e:
+                print("launch anatomy not measured: %r" % (e,), file=sys.stderr)
+        col_bytes = (n_local + 3) // 4
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic["traffic_bytes_per_launch"] if traffic else None, "traffic_source": traffic_src,
+                "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
+                "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
+                "sweep_ms_per_iter": sweep_ms / K,
+                # the section-8(d) byte model counts eps once per MARKER from HBM; the kernel reads it once per column group from
+                # L2 / Infinity Cache, so `frac` can exceed 1 and bounds nothing.  What bounds the kernel, each with its distance:
+                "compulsory_bytes_per_launch": (M * K * col_bytes + nnz * 16 * n_local) / max(1, launches),
+                "hbm_frac_compulsory": (M * K * col_bytes + nnz * 16 * n_local) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "hbm_frac_measured": (traffic["traffic_bytes_per_launch"] / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "valu_issue_frac_whole_launch": valu["valu_issue_frac"] if valu else None,
+                "valu_source": valu_src,
+                "working_launches_per_iter": launches / K, "enqueued_launches_per_iter": enqueued / K,
+                "accepted_per_launch": accepted / max(1, launches),
+                "columns_streamed_per_accepted": streamed / max(1, accepted),
+                "columns_carried_per_accepted": carried / max(1, accepted)}
+        if anatomy:
+            loop = anatomy["entry_and_streaming_loop_us"]
+            roof["anatomy_us"] = anatomy
+            roof["fixed_us_per_launch"] = anatomy["period_us"] - loop
+            roof["streaming_share_of_launch"] = loop / anatomy["period_us"] if anatomy["period_us"] else None
+            if valu and loop > 0:
+                # the VALU instructions of a launch are issued almost entirely inside the streaming loop (the draw phase is one
+                # workgroup): issue-slot share while streaming = whole-launch share x period / loop time
+                roof["valu_frac_streaming"] = valu["valu_issue_frac"] * anatomy["period_us"] / loop
+        roof["bound_statement"] = ("latency + VALU issue: HBM carries %s of its peak; the streaming loop (%s of a launch) runs at %s of the VALU issue rate; "
+                                   "the rest of a launch is the serial hand-off and draw of one workgroup" % (
+                                       ("%.1f %%" % (100 * roof["hbm_frac_measured"])) if roof["hbm_frac_measured"] else "%.1f %% (compulsory bytes)" % (100 * roof["hbm_frac_compulsory"]),
+                                       ("%.0f %%" % (100 * roof["streaming_share_of_launch"])) if anatomy else "n/a",
+                                       ("%.0f %%" % (100 * roof["valu_frac_streaming"])) if roof.get("valu_frac_streaming") else "n/a"))
         out = {
             "metric": "Gibbs markers/sec/iter",
             "value": value,
@@ -449,14 +518,13 @@ def main():
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
                        "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
-                       "launches_per_iter": launches / K, "carried_columns_per_iter": sum(s["carried_columns"] for s, _ in stats) / K,
+                       "launches_per_iter": enqueued / K, "working_launches_per_iter": launches / K,
+                       "accepted_per_launch": accepted / max(1, launches), "columns_streamed_per_accepted": streamed / max(1, accepted),
+                       "carried_columns_per_iter": carried / K, "causal_frac": args.causal_frac,
+                       "tiles_per_workgroup": [min(s["tiles_per_workgroup_min"] for s, _ in stats), max(s["tiles_per_workgroup_max"] for s, _ in stats)],
                        "setup_s": t_setup,
                        **({"missing_rate": args.missing} if args.missing else {}), **({"options": args.opt} if args.opt else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(N, args.batch or (256 if (hi - lo) >= 200000 or world > 1 else 128), world),
-                         "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
-                         "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
-                         "sweep_ms_per_iter": sweep_ms / K},
+            "roofline": roof,
         }
         try:  # measured streaming ceiling beside the nominal peak: 2 GiB device copy, far beyond the Infinity Cache
             ceiling = dev.stream_ceiling(2 << 30, 10)

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_covariates", "hgibbs_cov_dot", "hgibbs_cov_update",
     "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_components", "hydra_chain_restore",
     "hydra_rng_to_boost_words", "hydra_rng_from_boost_words", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
-    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hgibbs_stream_ceiling", "hydra_chain_create",
+    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hgibbs_stream_ceiling", "hgibbs_debug_times", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
     # BayesW
@@ -37,7 +37,9 @@ class RngState(C.Structure):
 
 class SweepStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("nnz_updates", C.c_uint64), ("device_ms", C.c_double),
-                ("kernel_ms_avg", C.c_double), ("carried_columns", C.c_uint64)]
+                ("kernel_ms_avg", C.c_double), ("carried_columns", C.c_uint64), ("working_launches", C.c_uint64),
+                ("accepted_markers", C.c_uint64), ("streamed_columns", C.c_uint64), ("tiles_per_workgroup_min", C.c_uint32),
+                ("tiles_per_workgroup_max", C.c_uint32)]
 
 
 class RestartState(C.Structure):
@@ -133,6 +135,7 @@ def lib():
     L.hgibbs_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.hgibbs_last_sweep_stats.argtypes = [vp, C.POINTER(SweepStats)]
     L.hgibbs_stream_ceiling.argtypes = [vp, C.c_uint64, C.c_int, dp]
+    L.hgibbs_debug_times.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.hydra_chain_create.argtypes = [vp, C.POINTER(ModelDesc), dp, C.POINTER(vp)]
     L.hydra_chain_destroy.argtypes = [vp]
     L.hydra_chain_iterate.argtypes = [vp]
@@ -353,6 +356,13 @@ class Device:
     def set_option(self, name, value):
         check(self.L.hgibbs_set_option(self.h, name.encode(), int(value)))
 
+    def debug_times(self):
+        """The 48 stage-timestamp words of the sweep kernel's debug build (option debug_timing; 100 MHz ticks, accumulated
+        over the launches since the last call, which clears them); layout in hg_sweep.hip.h (sweep_draw_phase)."""
+        t = (C.c_uint64 * 48)()
+        check(self.L.hgibbs_debug_times(self.h, t))
+        return [int(x) for x in t]
+
     def sweep(self, order, sigmaE, sigmaG, estPi, adaV, rng):
         """rng: RngState, updated in place.  Returns (cass[G,K], nnz_updates)."""
         order = np.ascontiguousarray(order, dtype=np.int32)
@@ -369,7 +379,9 @@ class Device:
         s = SweepStats()
         check(self.L.hgibbs_last_sweep_stats(self.h, C.byref(s)))
         return {"launches": s.launches, "nnz_updates": s.nnz_updates, "device_ms": s.device_ms,
-                "kernel_ms_avg": s.kernel_ms_avg, "carried_columns": s.carried_columns}
+                "kernel_ms_avg": s.kernel_ms_avg, "carried_columns": s.carried_columns, "working_launches": s.working_launches,
+                "accepted_markers": s.accepted_markers, "streamed_columns": s.streamed_columns,
+                "tiles_per_workgroup_min": s.tiles_per_workgroup_min, "tiles_per_workgroup_max": s.tiles_per_workgroup_max}
 
 
 class Chain:

@@ -82,6 +82,9 @@ struct SweepDesc {
     uint32_t pad_;
     double carry_ev[3];     // (dbeta, mave, mstd) of the last pending event
     uint64_t carried_sum;   // columns carried so far (statistics)
+    uint64_t streamed_sum;  // batch columns whose dot was streamed (planned columns minus the carried ones), statistics
+    uint32_t tiles_min;     // fewest / most tile groups (4096 individuals) one workgroup streamed in a working launch of this sweep:
+    uint32_t tiles_max;     // > 1 means the loop's next-tile prefetch and the accumulation across tiles ran
 };
 
 // In-launch cross-GPU exchange (xGMI peer mailboxes, IPC-mapped).  Rank r's

@@ -219,6 +219,15 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
     return best;
 }
 
+// Slices (workgroups per column group) of a launch with nb batch columns: as many as keep every active workgroup
+// co-resident, at most slices_max; a workgroup then streams ceil(ntg / S) tile groups.
+__device__ __forceinline__ uint32_t sweep_slices(const SweepParams& p, uint32_t nb, uint32_t cpg)
+{
+    const uint32_t nactive = (nb + cpg - 1) / cpg > 0 ? (nb + cpg - 1) / cpg : 1u;
+    const uint32_t fit = p.resident / nactive;
+    return fit < p.slices_max ? (fit ? fit : 1u) : p.slices_max;
+}
+
 // Posterior of the batch columns [lo, hi) of segment `seg` (a5: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921), one
 // thread per (column j, step kk of the component walk): numerator of the column (dot, Gram corrections for the earlier
 // pivots' updates in order, old effect's term), log-likelihoods of all components in registers, then
@@ -585,6 +594,15 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         n.carry_n = carry_next;
+        {
+            const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, nb, p.cols_per_group);
+            const uint32_t tiles = (ntg + S - 1) / S;
+            n.streamed_sum += nb - ncarry;
+            if (nb > ncarry) {
+                n.tiles_min = tiles < n.tiles_min ? tiles : n.tiles_min;
+                n.tiles_max = tiles > n.tiles_max ? tiles : n.tiles_max;
+            }
+        }
         if (carry_next) {
             for (int c = 0; c < 3; ++c) n.carry_ev[c] = sh.ev[3 * stop_seg + c];
             n.carried_sum += carry_next;
@@ -765,14 +783,14 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
     // slices actually used: keep the active workgroups co-resident (3 per CU at this register
     // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
-    const uint32_t RES = p.resident; // co-resident workgroups of this build at this launch's LDS size (occupancy query on the host)
+    // p.resident: co-resident workgroups of this build at this launch's LDS size (occupancy query on the host)
     // Carried columns (the first ncarry of the batch: streamed by the previous launch, see SweepDesc::carry_n) skip the
     // dot product and only take one integer Gram term.  Slices stay uniform: the compute units' VALUs are shared by the
     // co-resident workgroups, so the cheap carried groups simply leave issue slots to the fresh ones (giving them fewer
     // slices instead was measured: no difference).
     constexpr bool CARRY = !MG;
     const uint32_t ncarry = (CARRY && p.carry_on && p.gram && pend) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
-    const uint32_t S = (RES / nactive) < p.slices_max ? ((RES / nactive) ? RES / nactive : 1u) : p.slices_max;
+    const uint32_t S = sweep_slices(p, nb, CPG);
     if (blockIdx.x >= S * nactive) return;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
     const uint32_t c0 = group * CPG;

@@ -713,22 +713,28 @@ int hgibbs_load_bed(hgibbs_t h, const uint8_t* bed_host, uint64_t stride_in, uin
         HIP_TRY(hipGetLastError());
     } else {
         // NA rows dropped: build the kept-row index list, then gather on the device in slabs of columns
-        uint32_t* d_idx = nullptr;
-        HIP_TRY(hipMalloc(&d_idx, (size_t)n_local * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpyAsync(d_idx, kept.data() + row_begin, (size_t)n_local * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        // (the two staging buffers are released on every exit, the error returns included)
+        struct Staging {
+            uint32_t* idx = nullptr;
+            uint8_t* src = nullptr;
+            ~Staging()
+            {
+                if (src) (void)hipFree(src);
+                if (idx) (void)hipFree(idx);
+            }
+        } st;
+        HIP_TRY(hipMalloc(&st.idx, (size_t)n_local * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(st.idx, kept.data() + row_begin, (size_t)n_local * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         const uint32_t slab = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(M, (256ull << 20) / std::max<uint64_t>(1, stride_in)));
-        uint8_t* d_src = nullptr;
-        HIP_TRY(hipMalloc(&d_src, (size_t)slab * stride_in));
+        HIP_TRY(hipMalloc(&st.src, (size_t)slab * stride_in));
         for (uint32_t m0 = 0; m0 < M; m0 += slab) {
             const uint32_t mc = std::min(slab, M - m0);
-            HIP_TRY(hipMemcpyAsync(d_src, bed_host + (size_t)m0 * stride_in, (size_t)mc * stride_in, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(st.src, bed_host + (size_t)m0 * stride_in, (size_t)mc * stride_in, hipMemcpyHostToDevice, h->stream));
             dim3 grid((uint32_t)((h->stride + 255) / 256), mc);
-            k_compact_bed<<<grid, 256, 0, h->stream>>>(d_src, stride_in, d_idx, h->bed + (size_t)m0 * h->stride, h->stride, n_local, mc);
+            k_compact_bed<<<grid, 256, 0, h->stream>>>(st.src, stride_in, st.idx, h->bed + (size_t)m0 * h->stride, h->stride, n_local, mc);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        HIP_TRY(hipFree(d_src));
-        HIP_TRY(hipFree(d_idx));
+        HIP_TRY(hipStreamSynchronize(h->stream)); // before ~Staging frees what the kernels read
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -1164,6 +1170,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     d0.cur = h->eps_cur;
     d0.rng_idx = rng->idx;
     d0.seq = h->batch_seq;
+    d0.tiles_min = 0xffffffffu;
     *h->desc_host = d0;
     HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream)); // staging buffers are on the host stack / pageable
@@ -1225,8 +1232,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K, nr);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
-    if (h->nranks > 1 && split && !h->comm)
-        return fail("hgibbs_sweep: %d ranks but no per-batch transport (hgibbs_comm_init for RCCL or hgibbs_p2p_import)", h->nranks);
+    if (h->nranks > 1 && split && !h->comm && !h->ext_fn)
+        return fail("hgibbs_sweep: %d ranks but no per-batch transport (hgibbs_comm_init for RCCL, hgibbs_comm_init_external or hgibbs_p2p_import)", h->nranks);
     p.sums_out = split ? h->sums : nullptr;
     p.p2p.nranks = use_p2p ? h->nranks : 0;
     p.p2p.rank = h->rank;
@@ -1298,7 +1305,10 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         for (int i = 0; i < n && !gexec; ++i) {
             launch_one();
             if (split) {
+                // the exchange step of src/BayesRRm.cpp:2456, on the batch rows: RCCL in-stream, or the caller's transport
+                // (hydra's own MPI_Allreduce, say) on a host copy -- a stream round trip per batch, the parity baseline
                 if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
+                else if (h->nranks > 1 && bulk_allreduce(h, h->sums, (size_t)nr * MAX_BATCH + 1, 0)) return 1;
                 if (mg) k_sweep_draw<2, 1><<<1, BLOCK, lds, h->stream>>>(p);
                 else if (tier == 4) k_sweep_draw<4, 0><<<1, BLOCK, lds, h->stream>>>(p);
                 else k_sweep_draw<2, 0><<<1, BLOCK, lds, h->stream>>>(p);
@@ -1334,7 +1344,14 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     h->stats.carried_columns = h->desc_host->carried_sum;
     if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep: %llu launches, %llu columns carried\n", (unsigned long long)total_launches, (unsigned long long)h->desc_host->carried_sum);
     h->stats.device_ms = ms;
-    h->stats.kernel_ms_avg = total_launches ? ms / (double)total_launches : 0.0;
+    // launches that did work (the chunks the host enqueues overshoot the end of the sweep by a few launches that find
+    // nothing left and return at once): the average below is taken over the working ones
+    h->stats.working_launches = h->desc_host->launches;
+    h->stats.accepted_markers = h->desc_host->accepted_sum;
+    h->stats.streamed_columns = h->desc_host->streamed_sum;
+    h->stats.tiles_per_workgroup_min = h->desc_host->tiles_max ? h->desc_host->tiles_min : 0u;
+    h->stats.tiles_per_workgroup_max = h->desc_host->tiles_max;
+    h->stats.kernel_ms_avg = h->desc_host->launches ? ms / (double)h->desc_host->launches : 0.0;
     return 0;
 }
 

@@ -158,16 +158,24 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value);
 /* Statistics of the last sweep: launches, markers per launch, device time of
  * the sweep in ms (HIP events on the sweep's stream). */
 typedef struct {
-    uint64_t launches;
+    uint64_t launches;        /* launches enqueued (the host enqueues in chunks: a few past the end of the sweep find nothing to do) */
     uint64_t nnz_updates;
     double device_ms;
-    double kernel_ms_avg; /* average duration of the dominant kernel's launches */
+    double kernel_ms_avg;     /* device_ms / working_launches: average period of the dominant kernel's working launches */
     uint64_t carried_columns; /* batch columns whose dot was handed on by the previous launch instead of being streamed again */
+    uint64_t working_launches; /* launches that accepted markers or applied a pending update */
+    uint64_t accepted_markers; /* == M after a complete sweep */
+    uint64_t streamed_columns; /* batch columns whose dot product was streamed (speculative ones included, carried ones not) */
+    uint32_t tiles_per_workgroup_min; /* tile groups of 4096 individuals one workgroup of the sweep kernel streamed per launch: */
+    uint32_t tiles_per_workgroup_max; /* > 1 means the loop's next-tile prefetch and cross-tile accumulation ran */
 } hgibbs_sweep_stats;
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
 /* measured streaming ceiling of this GPU: device-to-device copy of `bytes` (choose well above the 256 MB
  * Infinity Cache), `reps` times; GB/s counts bytes read + bytes written */
 int hgibbs_stream_ceiling(hgibbs_t h, uint64_t bytes, int reps, double* gbps);
+/* diagnostic: the 48 accumulated stage-timestamp words (100 MHz ticks) of the sweep kernel's build with option
+ * debug_timing = 1 since the last call (which clears them): bench.py's launch anatomy, tools/dbg_times.py */
+int hgibbs_debug_times(hgibbs_t h, uint64_t* out48);
 
 /* ======================================================================== */
 /* Host driver: the body of BayesRRm::runMpiGibbs (src/BayesRRm.cpp:933-2939)

@@ -1,26 +1,43 @@
 #!/bin/bash
-# One gpurun call that produces what profiles/ holds for a round: the default bench line, the kernel trace of the
-# same command (rocprofv3 --kernel-trace --stats) with the timed-region average of the sweep kernel, and the two PMC
-# passes (FETCH_SIZE, WRITE_SIZE; separate runs, counters only) behind roofline.traffic.
-# usage (on the GPU box, repo root): bash tools/profile_round.sh rNN
+# One gpurun call that produces what profiles/ holds for a round, all on the HEADLINE workload (config 4, M = 1 M):
+#   1. the default bench line;
+#   2. the kernel trace of the same command (rocprofv3 --kernel-trace --stats), summarised over the timed iterations;
+#   3. PMC passes over the same command, counters only, one group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass;
+#      SQ and GRBM counters in two more), each summarised over the dispatches of the TIMED iterations (the last
+#      launches_per_iter * steps dispatches of k_sweep_batch), and folded into <R>_c4_pmc_traffic.json / <R>_c4_pmc_valu.json,
+#      which bench.py quotes with their source.
+# usage (on the GPU box, repo root): bash tools/profile_round.sh rNN [steps] [warmup]
 set -e
-R=${1:-r01}
+R=${1:-r02}
+STEPS=${2:-3}
+WARM=${3:-2}
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
 rm -rf $O && mkdir -p $O
 python3 bench.py > $O/${R}_c4_bench.json 2> $O/bench.err
-echo "bench done"; cat $O/${R}_c4_bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/${R}_c4_bench_under_rocprof.json 2> $O/kt.err
+echo "bench done"; cut -c1-400 $O/${R}_c4_bench.json
+
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-anatomy > $O/${R}_c4_bench_under_rocprof.json 2> $O/kt.err
 DB=$(ls $O/kt/*results.db $O/kt/*/*results.db 2>/dev/null | head -1)
 L=$(python3 -c "import json; d=json.load(open('$O/${R}_c4_bench_under_rocprof.json')); print(int(round(d['config']['launches_per_iter']*d['steps'])))")
 python3 tools/rocpd_stats.py $DB $O/${R}_c4_kernel_stats.csv k_sweep_batch $L > $O/${R}_c4_kernel_timed_region.txt
 cat $O/${R}_c4_kernel_timed_region.txt
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $O/pmc_$C -o p -- python3 bench.py --M 60000 --steps 1 --warmup 2 --no-cpu-baseline > $O/pmc_$C.json 2> $O/pmc_$C.err
-  DBP=$(ls $O/pmc_$C/*results.db $O/pmc_$C/*/*results.db 2>/dev/null | head -1)
-  python3 tools/rocpd_pmc.py $DBP $C k_sweep_batch 1.0 > $O/${R}_c4_pmc_$C.txt
-  cat $O/${R}_c4_pmc_$C.txt
-done
-# the databases are large: keep the summaries only
-rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+rm -rf $O/kt
+echo "kernel trace done"
+
+pmc_pass () { # name, counters...
+  local NAME=$1; shift
+  rocprofv3 --pmc "$@" -d $O/pmc_$NAME -o p -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-anatomy > $O/pmc_$NAME.json 2> $O/pmc_$NAME.err
+  local DBP=$(ls $O/pmc_$NAME/*results.db $O/pmc_$NAME/*/*results.db 2>/dev/null | head -1)
+  local LP=$(python3 -c "import json; d=json.load(open('$O/pmc_$NAME.json')); print(int(round(d['config']['launches_per_iter']*d['steps'])))")
+  python3 tools/rocpd_pmc.py $DBP k_sweep_batch $LP > $O/${R}_c4_pmc_$NAME.txt
+  cat $O/${R}_c4_pmc_$NAME.txt | cut -c1-300
+  rm -rf $O/pmc_$NAME
+  echo "pmc pass $NAME done"
+}
+pmc_pass FETCH_SIZE FETCH_SIZE
+pmc_pass WRITE_SIZE WRITE_SIZE
+pmc_pass SQ1 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE
+pmc_pass SQ2 SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
+python3 tools/pmc_fold.py $O $R
 ls -la $O
