@@ -207,12 +207,12 @@ __global__ __launch_bounds__(BLOCK) void k_bw_marker_sums(const uint8_t* __restr
         const uint32_t c = (w >> (2 * k)) & 3u;
         double t = e[k];
         if (shifted) {
-            const double de = (c == 3u) ? d0 : ((c == 2u) ? d1 : ((c == 0u) ? d2 : 0.0));
+            const double de = (c == GC_G0) ? d0 : ((c == GC_G1) ? d1 : ((c == GC_G2) ? d2 : 0.0));
             t = (i0 + k < n_local) ? exp(alpha * (e[k] + de) - bw::EULER) : 0.0;
         }
         s += t;
-        s1 += (c == 2u) ? t : 0.0;
-        s2 += (c == 0u) ? t : 0.0;
+        s1 += (c == GC_G1) ? t : 0.0;
+        s2 += (c == GC_G2) ? t : 0.0;
     }
     s = wave_sum(s);
     s1 = wave_sum(s1);
@@ -297,11 +297,11 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
 #pragma unroll
             for (int k = 0; k < IPT; ++k) {
                 const uint32_t c = (w >> (2 * k)) & 3u;
-                const double de = (c == 3u) ? p.dv[0] : ((c == 2u) ? p.dv[1] : ((c == 0u) ? p.dv[2] : 0.0));
+                const double de = (c == GC_G0) ? p.dv[0] : ((c == GC_G1) ? p.dv[1] : ((c == GC_G2) ? p.dv[2] : 0.0));
                 const double t = (i0 + k < p.n_local) ? exp(p.alpha * (e[k] + de) - bw::EULER) : 0.0;
                 s += t;
-                s1 += (c == 2u) ? t : 0.0;
-                s2 += (c == 0u) ? t : 0.0;
+                s1 += (c == GC_G1) ? t : 0.0;
+                s2 += (c == GC_G2) ? t : 0.0;
             }
         }
         s = wave_sum(s);

@@ -5,8 +5,14 @@
 // Data layout in HBM (per GPU, individuals shard [row_begin,row_end)):
 //   bed    M columns x stride bytes, stride = n_pad/4, n_pad = N_local rounded
 //          up to 4096 (one 256-thread block = 4 wave tiles of 1024 individuals).
-//          PLINK 2-bit codes as on disk (src/data.cpp:1189-1200): 00 -> 2,
-//          10 -> 1, 11 -> 0, 01 -> missing.  Padding slots hold 01 (missing),
+//          Same 2 bits per individual at the same position as the PLINK file, but
+//          RE-CODED once at load (k_recode_bed) so that the field IS the weight of
+//          the dot product: 00 -> genotype 0, 01 -> 1, 10 -> 2, 11 -> missing
+//          (PLINK's own codes, src/data.cpp:1189-1200, are 11 -> 0, 10 -> 1, 00 -> 2,
+//          01 -> missing: new_hi = ~hi, new_lo = hi ^ lo, an involution away from the
+//          file's bytes; hgibbs_get_bed returns the file's codes).  The streaming loop
+//          then needs no code -> weight conversion at all, and the integer Gram terms
+//          come from eight bit operations per dword.  Padding slots hold 11 (missing),
 //          so they contribute to no sum and receive no update.
 //   eps    2 x n_pad doubles (double-buffered: a launch that applies a pending
 //          update reads buffer `cur` and writes `cur^1`), stored PERMUTED so
@@ -106,6 +112,8 @@ struct SweepParams {
     uint32_t M;
     double n_minus_1;      // (double)(N_global - 1)
     double n_total;        // (double)N_global
+    double eps_sum;        // sum of eps over ALL ranks at sweep start = s2 of every column without missing calls, for the whole sweep:
+                           // a marker update leaves it unchanged (columns are centred over their non-missing calls), see hgibbs_sweep
     int gram;              // 1: extend batches past the first predicted event with Gram-corrected dots
     const int32_t* order;
     // per-marker metadata gathered into SWEEP order once per sweep (k_gather_meta)
@@ -219,24 +227,39 @@ __device__ __forceinline__ void store_eps16(double* __restrict__ eps, uint32_t t
     for (int k = 0; k < 8; ++k) p[k * 64] = make_double2(e[2 * k], e[2 * k + 1]);
 }
 
+// device genotype codes (see the layout note at the top): the 2-bit field is the genotype, 3 = missing call
+constexpr uint32_t GC_G0 = 0u, GC_G1 = 1u, GC_G2 = 2u, GC_MISS = 3u;
+
+// PLINK byte <-> device byte (four 2-bit fields each): new_hi = ~hi, new_lo = hi ^ lo; the inverse is hi = ~new_hi, lo = hi ^ new_lo
+__host__ __device__ __forceinline__ uint32_t recode_plink_to_device(uint32_t w)
+{
+    const uint32_t h = (w >> 1) & 0x55555555u, l = w & 0x55555555u;
+    return ((~h & 0x55555555u) << 1) | (h ^ l);
+}
+__host__ __device__ __forceinline__ uint32_t recode_device_to_plink(uint32_t w)
+{
+    const uint32_t nh = (w >> 1) & 0x55555555u, nl = w & 0x55555555u;
+    const uint32_t h = ~nh & 0x55555555u;
+    return (h << 1) | (h ^ nl);
+}
+
 // bit-plane masks of one column dword (16 codes): bit 2s set iff code s is ...
 __device__ __forceinline__ void code_masks(uint32_t w, uint32_t& m1, uint32_t& m2, uint32_t& mm)
 {
-    uint32_t hi = w >> 1, lo = w;
-    m1 = hi & ~lo & 0x55555555u;   // code 10 -> genotype 1
-    m2 = ~hi & ~lo & 0x55555555u;  // code 00 -> genotype 2
-    mm = ~hi & lo & 0x55555555u;   // code 01 -> missing
+    const uint32_t hi = w >> 1, lo = w;
+    m1 = lo & ~hi & 0x55555555u;   // code 01 -> genotype 1
+    m2 = hi & ~lo & 0x55555555u;   // code 10 -> genotype 2
+    mm = hi & lo & 0x55555555u;    // code 11 -> missing
 }
 
 // weights of one column dword (16 codes), 2-bit fields: gw = g*nm in {0,1,2}
-// (what dotp_lut_a*dotp_lut_b tabulate), nm = non-missing in {0,1} (dotp_lut_b)
+// (what dotp_lut_a*dotp_lut_b tabulate), nm = non-missing in {0,1} (dotp_lut_b).
+// For a column without missing calls gw == w: the loop uses the loaded dword as it is.
 __device__ __forceinline__ void code_weights(uint32_t w, uint32_t& gw, uint32_t& nm)
 {
-    const uint32_t hi = w >> 1, lo = w;
-    const uint32_t m1 = hi & ~lo & 0x55555555u;  // code 10 -> genotype 1
-    const uint32_t m2 = ~hi & ~lo & 0x55555555u; // code 00 -> genotype 2
-    gw = m1 | (m2 << 1);
-    nm = ~(~hi & lo) & 0x55555555u;              // everything but code 01
+    const uint32_t mm = w & (w >> 1) & 0x55555555u; // code 11
+    gw = w & ~(mm | (mm << 1));
+    nm = ~mm & 0x55555555u;
 }
 
 // a8 on registers: eps_s += {v0,v1,v2,0}[g_s]
@@ -245,7 +268,7 @@ __device__ __forceinline__ void apply_update16(uint32_t w, double v0, double v1,
 #pragma unroll
     for (int s = 0; s < IPT; ++s) {
         uint32_t c = (w >> (2 * s)) & 3u;
-        double v = (c == 3u) ? v0 : ((c == 2u) ? v1 : ((c == 0u) ? v2 : 0.0));
+        double v = (c == GC_G0) ? v0 : ((c == GC_G1) ? v1 : ((c == GC_G2) ? v2 : 0.0));
         e[s] = e[s] + (0.0 + v);
     }
 }

@@ -58,7 +58,7 @@ struct SweepShared {
     uint32_t* mt;      // MT_BUF words: current + next MT19937 block
     double* zig_nx;    // 129 + 129: normal Ziggurat layers staged for the draw
     double* zig_ny;
-    double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns (+ sum of eps)
+    double* wpart;     // [BLOCK_WAVES][wstride] per-wave partials of this block's columns
     double* tot;       // NROW*bcap + 1 reduced sums
     double* thr;       // [bcap][K-1]
     double* numf;      // [bcap] full numerator of a column once its posterior is evaluated (dot, Gram corrections, old effect's term)
@@ -342,7 +342,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         // A column without missing calls has s2 == sum of eps, bit for bit
         // (same lanes, same order), so it is not accumulated per column.
         const double s1 = sh.tot[NR * tid];
-        const double s2 = mm.miss ? sh.tot[NR * tid + 1] : sh.tot[NR * sh.bcap];
+        const double s2 = mm.miss ? sh.tot[NR * tid + 1] : p.eps_sum;
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
         if constexpr (CARRY) {
             // a carried column: the dot the previous launch handed on (corrected for every update but the last pending one)
@@ -673,13 +673,23 @@ __device__ __forceinline__ void fma_slots4(uint32_t g0, uint32_t g1, uint32_t g2
     (fma_slot4<S>(g0, g1, g2, g3, e[S], a0, a1, a2, a3), ...);
 }
 
-// sum over the 16 slots of gw_a * gw_b (2-bit fields with values 0,1,2): integer Gram term
-__device__ __forceinline__ uint32_t gram16(uint32_t ga, uint32_t gb)
+// Integer Gram terms on the device codes.  A weight dword holds 16 genotypes g in {0,1,2} as 2-bit fields (b1 b0).  Its
+// "x form" keeps b1 and puts u = [g >= 1] = b0 | b1 in the even bit: g = u + v with v = [g == 2] = b1, so
+//     sum_i g_a g_p = popc(x_a & UU_p) + popc(x_a & VV_p),
+// UU_p / VV_p being u_p / v_p replicated into both bits of every field: two ANDs and two accumulating popcounts per
+// (column, pivot) and dword, one more AND-OR + shift per column for x_a, a handful per pivot and tile for UU, VV.
+__device__ __forceinline__ uint32_t gram_xform(uint32_t gw) { return gw | ((gw >> 1) & 0x55555555u); }
+struct GramPivot {
+    uint32_t uu, vv;
+};
+__device__ __forceinline__ GramPivot gram_pivot(uint32_t gw)
 {
-    const uint32_t la = ga & 0x55555555u, ha = (ga >> 1) & 0x55555555u;
-    const uint32_t lb = gb & 0x55555555u, hb = (gb >> 1) & 0x55555555u;
-    return (uint32_t)__popc(la & lb) + 2u * (uint32_t)(__popc(la & hb) + __popc(ha & lb)) + 4u * (uint32_t)__popc(ha & hb);
+    const uint32_t ue = (gw | (gw >> 1)) & 0x55555555u, vo = gw & 0xAAAAAAAAu;
+    return GramPivot{ue | (ue << 1), vo | (vo >> 1)};
 }
+__device__ __forceinline__ uint32_t gram16x(uint32_t xa, const GramPivot& p) { return (uint32_t)__popc(xa & p.uu) + (uint32_t)__popc(xa & p.vv); }
+// the same from two weight dwords (tests of the identity, single-marker helpers)
+__device__ __forceinline__ uint32_t gram16(uint32_t ga, uint32_t gb) { return gram16x(gram_xform(ga), gram_pivot(gb)); }
 
 // Cross-GPU sum of the batch rows held in sh.tot, inside the launch: push my
 // rows into every rank's mailbox (system-scope stores over xGMI), publish one
@@ -692,13 +702,13 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
 {
     const int tid = threadIdx.x;
     const int nr = p.p2p.nranks, me = p.p2p.rank;
-    const uint32_t nrows = NR * nb + 1;
+    const uint32_t nrows = NR * nb;
     const uint32_t parity = (uint32_t)(d.seq & 1ull);
     const unsigned long long epoch = d.seq + 1ull;
     const size_t slot = (size_t)(parity * MAX_RANKS + (uint32_t)me) * ROWS_CAP;
     for (uint32_t it = tid; it < nrows * (uint32_t)nr; it += BLOCK) {
         const uint32_t dst = it / nrows, rr = it % nrows;
-        const double v = sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr];
+        const double v = sh.tot[rr];
         __hip_atomic_store(p.p2p.data[dst] + slot + rr, v, HG_RLX_SYSTEM);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -741,7 +751,7 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
 #pragma unroll
             for (int r = 0; r < MAX_RANKS; ++r)
                 if (r < nr) acc += v[i][r];
-            if (rr < nrows) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = acc;
+            if (rr < nrows) sh.tot[rr] = acc;
         }
     }
     __syncthreads();
@@ -804,14 +814,14 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     if (pend && tid < 16 * SEG) { // entry (c1 << 2 | c0) of pending update q: the addends of two neighbouring individuals
         const int q = tid >> 4;
         const double* pv = p.desc->pv[q];
-        auto addend = [&](uint32_t c) { return 0.0 + ((c == 3u) ? pv[0] : ((c == 2u) ? pv[1] : ((c == 0u) ? pv[2] : 0.0))); };
+        auto addend = [&](uint32_t c) { return 0.0 + ((c == GC_G0) ? pv[0] : ((c == GC_G1) ? pv[1] : ((c == GC_G2) ? pv[2] : 0.0))); };
         sh.pvt[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
     }
     if (dbgp && blockIdx.x == 0 && tid == 0) dbgp[0] = wall_clock64();
     const unsigned long long t_entry = dbgp ? wall_clock64() : 0ull;
 
     unsigned long long t_loop = 0ull;
-    double a1[CPG], a2[CPG], sall = 0.0;
+    double a1[CPG], a2[CPG];
     // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields
     // (a lane adds at most 64 per tile; the host keeps tiles per lane below 1000): ag01 = pivot 0 | pivot 1 << 16
     uint32_t ag01[CPG], ag2[CPG];
@@ -909,13 +919,29 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 for (int q = 0; q < SEG; ++q)
                     if (q < npend) wpn[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tilen << 8) + voff);
             }
-            uint32_t gwp[SEG - 1], nmp[SEG - 1];
+            // weights of a column dword: the device code IS the weight; only missing calls (code 11) have to be cleared
+            auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
+                if constexpr (NOMISS) {
+                    gwd = wd;
+                    nmd = 0x55555555u;
+                } else {
+                    code_weights(wd, gwd, nmd);
+                }
+            };
+            GramPivot gpv[SEG - 1];
+            uint32_t nmp[SEG - 1], xp0 = 0u; // MG: non-missing mask of the pivot, x form of pivot 0
 #pragma unroll
             for (int q = 0; q < SEG - 1; ++q) {
-                gwp[q] = nmp[q] = 0u;
-                if (q < ng) code_weights(wpiv[q], gwp[q], nmp[q]);
+                gpv[q] = GramPivot{0u, 0u};
+                nmp[q] = 0u;
+                if (q < ng) {
+                    uint32_t gwq;
+                    weights(wpiv[q], gwq, nmp[q]);
+                    gpv[q] = gram_pivot(gwq);
+                    if (MG && q == 0) xp0 = gram_xform(gwq);
+                }
             }
-            uint32_t gwcar = 0u; // weights of the LAST pending column: the event the carried dots are not yet corrected for
+            GramPivot gcar{0u, 0u}; // the LAST pending column: the event the carried dots are not yet corrected for
             if (pend) { // the previous launch's event(s), in order
 #pragma unroll
                 for (int q = 0; q < SEG; ++q)
@@ -923,20 +949,17 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 if (first_group) store_eps16(eps_out, tile, lane, e);
                 if constexpr (CARRY) {
                     if (ccar[0]) { // carried columns are a prefix of the batch: the group has one iff its first column is
-                        uint32_t wl = wp[0], nml;
+                        uint32_t wl = wp[0], gwl, nml;
 #pragma unroll
                         for (int q = 1; q < SEG; ++q) wl = (q == npend - 1) ? wp[q] : wl;
-                        code_weights(wl, gwcar, nml);
+                        weights(wl, gwl, nml);
+                        gcar = gram_pivot(gwl);
                     }
                 }
             }
-            if (first_group) {
-#pragma unroll
-                for (int i = 0; i < IPT; ++i) sall += e[i];
-            }
             uint32_t gw[CPG], nm[CPG];
 #pragma unroll
-            for (int c = 0; c < CPG; ++c) code_weights(w[c], gw[c], nm[c]);
+            for (int c = 0; c < CPG; ++c) weights(w[c], gw[c], nm[c]);
             // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds
             // its slots in increasing order
             if constexpr (CPG % 4 == 0) {
@@ -960,22 +983,24 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                         for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
                     }
                 }
+                const bool need_x = cseg[c] > 0 || (CARRY && ccar[c]);
+                const uint32_t xc = need_x ? gram_xform(gw[c]) : 0u;
                 if (cseg[c] > 0) {
-                    uint32_t g = gram16(gw[c], gwp[0]);
-                    if constexpr (MG) { // B, C, D: popcounts on the bit planes (weights 1 and 2 of the 2-bit fields)
-                        const uint32_t lj = gw[c] & 0x55555555u, hj = (gw[c] >> 1) & 0x55555555u;
-                        const uint32_t lp = gwp[0] & 0x55555555u, hp = (gwp[0] >> 1) & 0x55555555u;
-                        g |= ((uint32_t)__popc(lj & nmp[0]) + 2u * (uint32_t)__popc(hj & nmp[0])) << 16;
-                        ag2[c] += ((uint32_t)__popc(nm[c] & lp) + 2u * (uint32_t)__popc(nm[c] & hp)) | ((uint32_t)__popc(nm[c] & nmp[0]) << 16);
+                    uint32_t g = gram16x(xc, gpv[0]);
+                    if constexpr (MG) {
+                        // B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p: popcounts against masks replicated into both bits
+                        const uint32_t nmp2 = nmp[0] | (nmp[0] << 1), nmj2 = nm[c] | (nm[c] << 1);
+                        g |= (uint32_t)__popc(xc & nmp2) << 16;
+                        ag2[c] += (uint32_t)__popc(nmj2 & xp0) | ((uint32_t)__popc(nm[c] & nmp[0]) << 16);
                     }
                     if constexpr (SEG > 2) {
-                        if (cseg[c] > 1) g |= gram16(gw[c], gwp[1]) << 16;
-                        if (cseg[c] > 2) ag2[c] += gram16(gw[c], gwp[SEG > 3 ? 2 : 0]);
+                        if (cseg[c] > 1) g |= gram16x(xc, gpv[1]) << 16;
+                        if (cseg[c] > 2) ag2[c] += gram16x(xc, gpv[SEG > 3 ? 2 : 0]);
                     }
                     ag01[c] += g;
                 }
                 if constexpr (CARRY) {
-                    if (ccar[c]) ag2[c] += gram16(gw[c], gwcar) << 16;
+                    if (ccar[c]) ag2[c] += gram16x(xc, gcar) << 16;
                 }
             }
             if (tgn < ntg) {
@@ -1014,10 +1039,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 }
             }
         }
-        if (first_group) {
-            const double t = wave_sum(sall);
-            if (lane == 0) sh.wpart[wave * sh.wstride + NR * CPG] = t;
-        }
     }
     __syncthreads();
 
@@ -1030,14 +1051,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             v += sh.wpart[2 * sh.wstride + t];
             v += sh.wpart[3 * sh.wstride + t];
             __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + (NR * c0 + t), v, HG_RLX_AGENT);
-        }
-        if (first_group && tid == BLOCK - 1) {
-            const uint32_t t = NR * CPG;
-            double v = sh.wpart[t];
-            v += sh.wpart[sh.wstride + t];
-            v += sh.wpart[2 * sh.wstride + t];
-            v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + NR * MAX_BATCH, v, HG_RLX_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
@@ -1055,12 +1068,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     __syncthreads();
     if (!sh.flags[F_LAST]) return;
     {
-        const uint32_t nrowg = NR * ncol + (first_group ? 1u : 0u); // group 0 also owns the sum of eps
+        const uint32_t nrowg = NR * ncol;
         const uint32_t half = tid >> 7, rl = tid & 127u;
         for (uint32_t rr0 = 0; rr0 < nrowg; rr0 += 128) {
             const uint32_t rr = rr0 + rl;
             const bool live = rr < nrowg;
-            const uint32_t r = (first_group && rr == NR * ncol) ? NR * MAX_BATCH : NR * c0 + rr;
+            const uint32_t r = NR * c0 + rr;
             const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
             double v[32];
 #pragma unroll
@@ -1094,18 +1107,18 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     }
     {
         // all rows of this thread in flight at once
-        constexpr int NRT = (NR * MAX_BATCH + BLOCK) / BLOCK;
-        const uint32_t nrows = NR * nb + 1;
+        constexpr int NRT = (NR * MAX_BATCH + BLOCK - 1) / BLOCK;
+        const uint32_t nrows = NR * nb;
         double v[NRT];
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
             const uint32_t rr = (uint32_t)tid + (uint32_t)i * BLOCK;
-            v[i] = (rr < nrows) ? __hip_atomic_load(p.totals + ((rr == NR * nb) ? NR * MAX_BATCH : rr), HG_RLX_AGENT) : 0.0;
+            v[i] = (rr < nrows) ? __hip_atomic_load(p.totals + rr, HG_RLX_AGENT) : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
             const uint32_t rr = (uint32_t)tid + (uint32_t)i * BLOCK;
-            if (rr < nrows) sh.tot[(rr == NR * nb) ? NR * sh.bcap : rr] = v[i];
+            if (rr < nrows) sh.tot[rr] = v[i];
         }
     }
     if (tid == 0) {
@@ -1124,12 +1137,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         }
     }
     if (p.sums_out) { // multi-GPU: hand the local sums to the all-reduce
-        for (int r = tid; r < NR * MAX_BATCH + 1; r += BLOCK) {
-            double v = 0.0;
-            if (r < NR * (int)nb) v = sh.tot[r];
-            if (r == NR * MAX_BATCH) v = sh.tot[NR * sh.bcap];
-            p.sums_out[r] = v;
-        }
+        for (int r = tid; r < NR * MAX_BATCH; r += BLOCK) p.sums_out[r] = (r < NR * (int)nb) ? sh.tot[r] : 0.0;
         return;
     }
     sweep_draw_phase<SEG, MG, DBG>(p, d, nbs, sh);
@@ -1157,7 +1165,6 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     stage_marker_meta(p, d, nb2, threadIdx.x, sh);
     stage_rng(p, sh, threadIdx.x);
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
-    if (threadIdx.x == 0) sh.tot[NR * sh.bcap] = p.sums_out[NR * MAX_BATCH];
     __syncthreads();
     sweep_draw_phase<SEG, MG, 0>(p, d, nbs, sh);
 }

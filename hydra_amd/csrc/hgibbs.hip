@@ -203,13 +203,13 @@ __global__ void k_synth_bed(uint8_t* bed, uint64_t stride, uint32_t n_local, uin
     uint32_t byte = 0;
     for (int s = 0; s < 4; ++s) {
         const uint64_t il = b * 4 + s;
-        uint32_t code = 1u; // missing (padding)
+        uint32_t code = GC_MISS; // padding
         if (il < n_local) {
             const uint64_t ig = (uint64_t)row_begin + il;
             const uint64_t hsh = mix64(seed + (uint64_t)marker * 0x9E3779B1ull + ig * 0xD1B54A32D192ED03ull);
             const uint32_t ug = (uint32_t)(hsh >> 32), um = (uint32_t)hsh;
-            if (um < miss_thr) code = 1u;
-            else code = (ug < t0) ? 3u : ((ug < t1) ? 2u : 0u); // genotype 0 / 1 / 2
+            if (um < miss_thr) code = GC_MISS;
+            else code = (ug < t0) ? GC_G0 : ((ug < t1) ? GC_G1 : GC_G2); // device codes (hg_kernels.h): the field is the genotype
         }
         byte |= code << (2 * s);
     }
@@ -227,6 +227,14 @@ __global__ void k_fix_padding(uint8_t* bed, uint64_t stride, uint32_t n_local, u
         for (uint32_t s = n_local & 3u; s < 4; ++s) v = (uint8_t)((v & ~(3u << (2 * s))) | (1u << (2 * s)));
         bed[(uint64_t)marker * stride + bfirst] = v;
     }
+}
+
+// PLINK codes -> device codes (hg_kernels.h: the 2-bit field becomes the genotype itself), in place, dword-wise over
+// the whole padded buffer; run once after the file's bytes are in HBM.  HBM-bound one-pass kernel.
+__global__ void k_recode_bed(uint32_t* __restrict__ bed, uint64_t ndwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndwords; i += stride) bed[i] = recode_plink_to_device(bed[i]);
 }
 
 // NA-phenotype row removal: gather the kept 2-bit fields of a full column into
@@ -736,6 +744,9 @@ int hgibbs_load_bed(hgibbs_t h, const uint8_t* bed_host, uint64_t stride_in, uin
         }
         HIP_TRY(hipStreamSynchronize(h->stream)); // before ~Staging frees what the kernels read
     }
+    // the file's bytes (padding included: PLINK's missing code) are in place: re-code them for the kernels
+    k_recode_bed<<<4096, 256, 0, h->stream>>>(reinterpret_cast<uint32_t*>(h->bed), (uint64_t)M * h->stride / 4);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -778,6 +789,11 @@ int hgibbs_get_bed(hgibbs_t h, uint32_t m0, uint32_t mcount, uint8_t* out_host, 
     const size_t width = ((size_t)h->n_local + 3) / 4;
     if (out_stride < width) return fail("hgibbs_get_bed: out_stride too small");
     HIP_TRY(hipMemcpy2D(out_host, out_stride, h->bed + (size_t)m0 * h->stride, h->stride, width, mcount, hipMemcpyDeviceToHost));
+    // device codes -> the file's (PLINK) codes; slots past n_local in the last byte come back as PLINK's missing code
+    for (uint32_t m = 0; m < mcount; ++m) {
+        uint8_t* row = out_host + (size_t)m * out_stride;
+        for (size_t b = 0; b < width; ++b) row[b] = (uint8_t)recode_device_to_plink(row[b]);
+    }
     return 0;
 }
 
@@ -849,10 +865,9 @@ int hgibbs_get_residual(hgibbs_t h, double* eps_host)
     return 0;
 }
 
-int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
+// sum of eps and of eps^2 over all ranks, fixed order: out[0], out[1]
+static int reduce_eps_all(hgibbs_ctx* h, double out[2])
 {
-    if (!h || !h->bed) return fail("hgibbs_reduce_eps: no data loaded");
-    HIP_TRY(hipSetDevice(h->device));
     const uint32_t nblk = h->n_pad / BLOCK_IND;
     k_reduce_eps<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], h->n_pad, h->scratch);
     k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 2, h->sums);
@@ -860,8 +875,19 @@ int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
     if (bulk_allreduce(h, h->sums, 2, 0)) return 1;
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (sum) *sum = h->scratch_host[0];
-    if (sqn) *sqn = h->scratch_host[1];
+    out[0] = h->scratch_host[0];
+    out[1] = h->scratch_host[1];
+    return 0;
+}
+
+int hgibbs_reduce_eps(hgibbs_t h, double* sum, double* sqn)
+{
+    if (!h || !h->bed) return fail("hgibbs_reduce_eps: no data loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    double r[2];
+    if (reduce_eps_all(h, r)) return 1;
+    if (sum) *sum = r[0];
+    if (sqn) *sqn = r[1];
     return 0;
 }
 
@@ -1184,6 +1210,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.M = M;
     p.n_minus_1 = dNm1;
     p.n_total = (double)h->n_global;
+    {
+        // s2 = sum_i nm_i eps_i of a column WITHOUT missing calls is the plain sum of eps (src/BayesRRm.cpp:1788 with
+        // every nm_i = 1).  A marker update adds mstd (g_i - mave) nm_i dbeta to eps_i, and mave is the mean of g over the
+        // marker's non-missing calls, so the update's sum over i is zero: the sum of eps is the same before and after
+        // every update of the sweep up to the rounding of the adds (~1e-16 of |eps|, random sign; far below the 1e-9
+        // the dots are held to).  It is therefore reduced once per sweep, in fixed order and over all ranks, instead of
+        // once per launch by the streaming loop.  Columns with missing calls keep their own masked sum per marker.
+        double r[2];
+        if (reduce_eps_all(h, r)) return 1;
+        p.eps_sum = r[0];
+    }
     p.gram = h->gram ? 1 : 0;
     p.order = h->order;
     p.beta = h->beta;
@@ -1307,8 +1344,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
             if (split) {
                 // the exchange step of src/BayesRRm.cpp:2456, on the batch rows: RCCL in-stream, or the caller's transport
                 // (hydra's own MPI_Allreduce, say) on a host copy -- a stream round trip per batch, the parity baseline
-                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH + 1, ncclDouble, ncclSum, h->comm, h->stream));
-                else if (h->nranks > 1 && bulk_allreduce(h, h->sums, (size_t)nr * MAX_BATCH + 1, 0)) return 1;
+                if (h->comm) NCCL_TRY(ncclAllReduce(h->sums, h->sums, nr * MAX_BATCH, ncclDouble, ncclSum, h->comm, h->stream));
+                else if (h->nranks > 1 && bulk_allreduce(h, h->sums, (size_t)nr * MAX_BATCH, 0)) return 1;
                 if (mg) k_sweep_draw<2, 1><<<1, BLOCK, lds, h->stream>>>(p);
                 else if (tier == 4) k_sweep_draw<4, 0><<<1, BLOCK, lds, h->stream>>>(p);
                 else k_sweep_draw<2, 0><<<1, BLOCK, lds, h->stream>>>(p);

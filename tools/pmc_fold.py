@@ -51,13 +51,16 @@ b1 = bench_of("SQ1")
 # GRBM_GUI_ACTIVE counts shader-engine clock cycles the GPU was busy with the dispatch.  A SIMD issues at most one VALU
 # instruction per quad-cycle, so the chip-wide VALU issue capacity of a launch is GUI_ACTIVE / 4 quad-cycles x 1024 SIMDs
 # (256 CUs x 4): valu_issue_frac = SQ_ACTIVE_INST_VALU / that.
-gui = s1["GRBM_GUI_ACTIVE"]["mean_work"]
+# rocprofv3 sums a counter over its instances: GRBM_GUI_ACTIVE comes back as the sum over the 8 XCDs (its per-launch value / 8
+# x the launch's duration gives the engine clock, 2.1-2.4 GHz), SQ counters as the sum over all SIMDs' waves
+XCDS = 8
+gui = s1["GRBM_GUI_ACTIVE"]["mean_work"] / XCDS
 cap = gui / 4.0 * 1024.0
 json.dump({
     "command": cmd + " (two SQ passes)", "workload": b1["config"]["workload"], "N": b1["config"]["N"], "M": b1["config"]["M"],
     "steps": b1["steps"], "warmup": b1["warmup"], "dispatches_timed": s1["SQ_INSTS_VALU"]["n"],
     "per_working_launch_mean": {k: v["mean_work"] for k, v in {**s1, **{k: v for k, v in s2.items() if k != "GRBM_GUI_ACTIVE"}}.items()},
-    "GRBM_GUI_ACTIVE_second_pass": s2["GRBM_GUI_ACTIVE"]["mean_work"],
+    "GRBM_GUI_ACTIVE_second_pass": s2["GRBM_GUI_ACTIVE"]["mean_work"], "gui_active_cycles_per_xcd": gui,
     "units": "SQ_ACTIVE_INST_*, SQ_WAVE_CYCLES, SQ_WAIT_*: quad-cycles summed over waves; SQ_BUSY_CYCLES: cycles summed over shader engines / XCDs as rocprofv3 "
              "reports it; GRBM_GUI_ACTIVE: cycles; SQ_INSTS_*: wave-instructions",
     "valu_issue_frac": s1["SQ_ACTIVE_INST_VALU"]["mean_work"] / cap if cap else None,
