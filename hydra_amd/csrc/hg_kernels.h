@@ -109,6 +109,7 @@ struct SweepParams {
     double* eps0;
     double* eps1;
     uint32_t n_pad;        // padded local individuals
+    uint32_t n_local;      // individuals of this shard (slots [n_local, n_pad) are padding: code 11, eps 0)
     uint32_t M;
     double n_minus_1;      // (double)(N_global - 1)
     double n_total;        // (double)N_global

@@ -919,10 +919,19 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 for (int q = 0; q < SEG; ++q)
                     if (q < npend) wpn[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tilen << 8) + voff);
             }
-            // weights of a column dword: the device code IS the weight; only missing calls (code 11) have to be cleared
+            // weights of a column dword: the device code IS the weight; only missing calls (code 11) have to be cleared.
+            // Data without missing calls holds that code in the padding slots behind the shard's last individual only
+            // (at most one tile group): there the lane's mask of valid slots clears it, everywhere else the dword is used as loaded.
+            uint32_t keep = 0xffffffffu;
+            const bool pad_tile = NOMISS && (tile + 1u) * (uint32_t)TILE > p.n_local; // wave-uniform
+            if (pad_tile) {
+                const uint32_t i0 = tile * (uint32_t)TILE + ((uint32_t)lane << 4);
+                const uint32_t nv = i0 >= p.n_local ? 0u : (p.n_local - i0 >= 16u ? 16u : p.n_local - i0);
+                keep = nv >= 16u ? 0xffffffffu : ((1u << (2u * nv)) - 1u);
+            }
             auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
                 if constexpr (NOMISS) {
-                    gwd = wd;
+                    gwd = pad_tile ? (wd & keep) : wd;
                     nmd = 0x55555555u;
                 } else {
                     code_weights(wd, gwd, nmd);

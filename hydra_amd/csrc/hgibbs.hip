@@ -1207,6 +1207,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.eps0 = h->eps[0];
     p.eps1 = h->eps[1];
     p.n_pad = h->n_pad;
+    p.n_local = h->n_local;
     p.M = M;
     p.n_minus_1 = dNm1;
     p.n_total = (double)h->n_global;

@@ -258,7 +258,7 @@ def test_two_ranks_per_marker_allreduce_is_the_parity_baseline(oracle):
     """north_star's scheme verbatim: one all-reduce of (s1, s2) per marker (batch = 1, split path), two ranks.
     Slow by construction (a stream round trip per marker); kept as the baseline every faster exchange is compared
     with.  Small M, shards still beyond 49 152 individuals."""
-    _two_ranks_vs_oracle(oracle, "external", M=60, N=110004, iters=2, opts={"batch": 1})
+    _two_ranks_vs_oracle(oracle, "external", M=60, N=110004, iters=2, opts={"batch": 1, "slices": 7}, min_tiles=2)
 
 
 def test_two_ranks_rccl_on_one_device_is_refused_or_matches(oracle):
