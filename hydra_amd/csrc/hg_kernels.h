@@ -59,11 +59,22 @@ constexpr int MAX_K = 8;                 // mixture components incl. zero
 constexpr int HT_LDS = 64;               // hyper tables are staged in LDS when G*K <= this
 constexpr int NSUM = 2;                  // sums per batch column: s1 = sum g*nm*eps, s2 = sum nm*eps
 constexpr int MAX_SEG = 4;               // segments per launch: each ends on a predicted event (its pivot) and hands one pending update on
-constexpr int NROW = NSUM + 4;           // most rows per batch column: s1, s2 and either one Gram term per earlier pivot (MAX_SEG - 1) plus the carry
-                                         // term, or, in the two-segment build that takes missing calls through the extension, the four terms A, B, C, D
-// rows per batch column of a kernel build: s1, s2, then the Gram terms: one per earlier pivot and the carry term, or A, B, C, D
-__host__ __device__ constexpr int sweep_rows(int seg, int mg) { return NSUM + (seg - 1) * (mg ? 4 : 1) + (mg ? 0 : 1); }
-constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // partial rows per slice (padded)
+constexpr int NROW = NSUM + 4;           // most rows per batch column in `totals`: s1, s2 and one Gram term per earlier pivot (MAX_SEG - 1) or, in the
+                                         // two-segment build that takes missing calls through the extension, the four terms A, B, C, D
+// rows per batch column of a kernel build in `totals`: s1 (for a carried column: its Gram correction G_j), s2, then per earlier pivot one
+// Gram term, or A, B, C, D
+__host__ __device__ constexpr int sweep_rows(int seg, int mg) { return NSUM + (seg - 1) * (mg ? 4 : 1); }
+// carried columns per Gram-only workgroup, and the rows such a group publishes per column (per pending update and per earlier pivot)
+__host__ __device__ constexpr int carried_cpg(int mg) { return mg ? 8 : 16; }
+__host__ __device__ constexpr int carried_rows(int seg, int mg) { return (seg + seg - 1) * (mg ? 4 : 1); }
+// row block of one group (slices x this many rows) in `partials`
+__host__ __device__ constexpr int group_rows(int cpg, int seg, int mg)
+{
+    return carried_cpg(mg) * carried_rows(seg, mg) > cpg * sweep_rows(seg, mg) ? carried_cpg(mg) * carried_rows(seg, mg) : cpg * sweep_rows(seg, mg);
+}
+constexpr int MAX_GROUPS = 1 + MAX_BATCH / 8 + MAX_BATCH / 2; // update group + Gram-only groups + fresh groups at their smallest sizes
+constexpr int PROWS_CAP = 10240;         // partial rows per slice: groups x group_rows of any build (checked on the host)
+constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // rows of `totals` (padded)
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
@@ -82,11 +93,11 @@ struct SweepDesc {
     uint64_t accepted_sum;  // total accepted markers (== cursor at the end)
     uint64_t seq;           // batches since the handle was created (epoch of the cross-GPU exchange)
     // carried dots: the first carry_n columns of the next batch were already streamed by this launch (they lay behind the
-    // event that ended it); their dots (corrected for every update but the last pending one) are in SweepParams::carry, and
-    // the next launch only takes their integer Gram term with that last pending column
+    // event that ended it); their dots against THIS launch's residual are in SweepParams::carry, and the next launch only
+    // takes their integer Gram terms with its pending columns (this launch's events)
     uint32_t carry_n;
     uint32_t pad_;
-    double carry_ev[3];     // (dbeta, mave, mstd) of the last pending event
+    double pend_ev[MAX_SEG][3]; // (dbeta, mave, mstd) of the pending updates: what the Gram correction of a carried dot needs
     uint64_t carried_sum;   // columns carried so far (statistics)
     uint64_t streamed_sum;  // batch columns whose dot was streamed (planned columns minus the carried ones), statistics
     uint32_t tiles_min;     // fewest / most tile groups (4096 individuals) one workgroup streamed in a working launch of this sweep:
@@ -142,10 +153,10 @@ struct SweepParams {
     SweepDesc* desc;
     double* carry;         // [MAX_BATCH] dots of the carried columns (written by the draw phase, read by the next one)
     uint32_t carry_on;     // 1: launches may hand dots of already streamed columns to the next one
-    double* partials;      // [S_CAP][ROWS_CAP], written sc1
+    double* partials;      // [S_CAP][PROWS_CAP]: per slice, one row block per group, written sc1
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals
-    uint32_t* gticket;     // [MAX_BATCH]: per column group, workgroups that have stored their partials
+    uint32_t* gticket;     // [MAX_GROUPS]: per group, workgroups that have stored their partials
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)
@@ -271,6 +282,53 @@ __device__ __forceinline__ void apply_update16(uint32_t w, double v0, double v1,
         uint32_t c = (w >> (2 * s)) & 3u;
         double v = (c == GC_G0) ? v0 : ((c == GC_G1) ? v1 : ((c == GC_G2) ? v2 : 0.0));
         e[s] = e[s] + (0.0 + v);
+    }
+}
+
+// LDS reads the compiler must not see.  The streaming loops keep LDS-DMA (global_load_lds) and register loads in flight
+// across iterations and wait on exact vmcnt values; the compiler cannot tell which LDS bytes a DMA writes, so before any
+// LDS read IT emits it waits for vmcnt(0) -- every load in flight, the prefetched tiles included.  Reads issued from inline
+// assembly are invisible to that rule; their lgkmcnt wait is placed by hand.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+template <int OFF>
+__device__ __forceinline__ d2_t lds_read128(uint32_t addr)
+{
+    d2_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a value an earlier inline-assembly load produced may be used only behind the wait that covers it: this empty statement
+// (volatile statements keep their order) makes every later use depend on a point behind that wait
+template <class V>
+__device__ __forceinline__ void pin_after_wait(V& v) { asm volatile("" : "+v"(v)); }
+
+// the 16 residuals of a lane from its wave's staging tile (lane-linear 1 KiB pieces, the permuted eps layout)
+__device__ __forceinline__ void lds_eps16(uint32_t tile_addr, int lane, double (&e)[IPT])
+{
+    const uint32_t a = tile_addr + ((uint32_t)lane << 4);
+    d2_t v0 = lds_read128<0>(a), v1 = lds_read128<1024>(a), v2 = lds_read128<2048>(a), v3 = lds_read128<3072>(a);
+    d2_t v4 = lds_read128<4096>(a), v5 = lds_read128<5120>(a), v6 = lds_read128<6144>(a), v7 = lds_read128<7168>(a);
+    lds_wait(); // eps is in registers: the staging tile may be overwritten
+    pin_after_wait(v0); pin_after_wait(v1); pin_after_wait(v2); pin_after_wait(v3);
+    pin_after_wait(v4); pin_after_wait(v5); pin_after_wait(v6); pin_after_wait(v7);
+    e[0] = v0.x; e[1] = v0.y; e[2] = v1.x; e[3] = v1.y; e[4] = v2.x; e[5] = v2.y; e[6] = v3.x; e[7] = v3.y;
+    e[8] = v4.x; e[9] = v4.y; e[10] = v5.x; e[11] = v5.y; e[12] = v6.x; e[13] = v6.y; e[14] = v7.x; e[15] = v7.y;
+}
+
+// apply_update16_lds with such reads: tab_addr = LDS address of the 16-entry pair table of one pending update
+__device__ __forceinline__ void apply_update16_asm(uint32_t w, uint32_t tab_addr, double (&e)[IPT])
+{
+    d2_t v[IPT / 2];
+#pragma unroll
+    for (int s = 0; s < IPT; s += 2) v[s >> 1] = lds_read128<0>(tab_addr + (((w >> (2 * s)) & 15u) << 4));
+    lds_wait();
+#pragma unroll
+    for (int s = 0; s < IPT; s += 2) {
+        pin_after_wait(v[s >> 1]);
+        e[s] = e[s] + v[s >> 1].x;
+        e[s + 1] = e[s + 1] + v[s >> 1].y;
     }
 }
 

@@ -76,6 +76,8 @@ struct SweepShared {
     double* red;       // 128 doubles: exchange buffer of the tail reduction
     double* ev;        // 3 per segment: (dbeta, mave, mstd) of the event that ended it
     double* pvl;       // 3*MAX_SEG: update constants of the events this launch hands on (draw phase)
+    double* pel;       // 3*MAX_SEG: (dbeta, mave, mstd) of the same events
+    double* pev;       // 3*MAX_SEG: (dbeta, mave, mstd) of the PENDING updates of this launch (staged from the descriptor)
     double2* pvt;      // [MAX_SEG][16]: the pending updates as a table over a PAIR of 2-bit codes (see apply_update16_lds); shares
                        // its 1 KiB with `red` (the table is dead once the streaming loop is over)
     int32_t* pmk;      // MAX_SEG: markers of the events this launch hands on
@@ -107,7 +109,7 @@ __host__ __device__ inline size_t sweep_lds_meta_bytes(uint32_t bcap)
 __host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr, uint32_t bcap)
 {
     size_t n = sweep_lds_meta_bytes(bcap);
-    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * MAX_SEG * 8 + 16;
+    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * 3 * MAX_SEG * 8 + 16;
     n += (size_t)BLOCK_WAVES * (nr * cpg + 1) * 8;
     return (n + 15) & ~(size_t)15;
 }
@@ -135,6 +137,8 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
     sh.scanf = q; q += 2 * BLOCK;
     sh.pvl = reinterpret_cast<double*>(q); q += 3 * MAX_SEG * 8;
+    sh.pel = reinterpret_cast<double*>(q); q += 3 * MAX_SEG * 8;
+    sh.pev = reinterpret_cast<double*>(q); q += 3 * MAX_SEG * 8;
     sh.pmk = reinterpret_cast<int32_t*>(q); q += 16;
     sh.wstride = nr * cpg + 1;
     sh.wpart = reinterpret_cast<double*>(q); q += (size_t)BLOCK_WAVES * sh.wstride * 8;
@@ -219,13 +223,25 @@ __device__ __forceinline__ uint32_t block_min_u32(const SweepShared& sh, uint32_
     return best;
 }
 
-// Slices (workgroups per column group) of a launch with nb batch columns: as many as keep every active workgroup
+// Slices (workgroups per group) of a launch with nactive groups: as many as keep every active workgroup
 // co-resident, at most slices_max; a workgroup then streams ceil(ntg / S) tile groups.
-__device__ __forceinline__ uint32_t sweep_slices(const SweepParams& p, uint32_t nb, uint32_t cpg)
+__device__ __forceinline__ uint32_t sweep_slices(const SweepParams& p, uint32_t nactive)
 {
-    const uint32_t nactive = (nb + cpg - 1) / cpg > 0 ? (nb + cpg - 1) / cpg : 1u;
-    const uint32_t fit = p.resident / nactive;
+    const uint32_t fit = p.resident / (nactive ? nactive : 1u);
     return fit < p.slices_max ? (fit ? fit : 1u) : p.slices_max;
+}
+
+// carried prefix of a batch of nb columns (their dots were handed on by the previous launch: SweepDesc::carry_n)
+__device__ __forceinline__ uint32_t sweep_carried(const SweepParams& p, const DescHead& d, uint32_t nb)
+{
+    return (p.carry_on && p.gram && d.pend_marker[0] >= 0) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
+}
+
+// groups of a launch: the update group (when updates are pending), Gram-only groups of the carried columns, fresh groups
+__device__ __forceinline__ uint32_t sweep_groups(const SweepParams& p, const DescHead& d, uint32_t nb, int mg)
+{
+    const uint32_t ncar = sweep_carried(p, d, nb), ccg = (uint32_t)carried_cpg(mg);
+    return (d.pend_marker[0] >= 0 ? 1u : 0u) + (ncar + ccg - 1) / ccg + (nb - ncar + p.cols_per_group - 1) / p.cols_per_group;
 }
 
 // Posterior of the batch columns [lo, hi) of segment `seg` (a5: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921), one
@@ -320,9 +336,11 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     const uint32_t idx0 = d.rng_idx;
     const bool need_next = idx0 + MAX_BATCH + 64 > (uint32_t)MT_N; // uniform
     if (need_next) mt_next_block(sh.mt, tid);
-    constexpr bool CARRY = !MG;
-    const bool carry_on = CARRY && p.carry_on && p.gram;
-    const uint32_t ncarry = (carry_on && d.pend_marker[0] >= 0) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
+    const bool carry_on = p.carry_on && p.gram;
+    const uint32_t ncarry = sweep_carried(p, d, nb);
+    int npend_in = 0; // pending updates this launch applied (what the carried dots were not yet corrected for)
+#pragma unroll
+    for (int q = 0; q < MAX_SEG; ++q) npend_in += d.pend_marker[q] >= 0 ? 1 : 0;
 
     // per-column state -> LDS, dot products from the reduced rows
     struct {
@@ -344,13 +362,16 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         const double s1 = sh.tot[NR * tid];
         const double s2 = mm.miss ? sh.tot[NR * tid + 1] : p.eps_sum;
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);
-        if constexpr (CARRY) {
-            // a carried column: the dot the previous launch handed on (corrected for every update but the last pending one)
-            // plus that event's dbeta * x_j'x_f, from the integer Gram term this launch took instead of the dot
-            if ((uint32_t)tid < ncarry) {
-                const double A = sh.tot[NR * tid + NR - 1];
-                sh.dp[tid] = p.carry[tid] + p.desc->carry_ev[0] * (mm.mstd * p.desc->carry_ev[2] * (A - p.n_total * (mm.mave * p.desc->carry_ev[1])));
+        // a carried column: the dot the previous launch handed on (against ITS residual) plus sum_q dbeta_q x_j'x_q over the
+        // updates applied since.  Row 0 holds G_j = sum_q dbeta_q mstd_j mstd_q A_jq (integer Gram terms, summed over ranks);
+        // without missing calls x_j'x_q = mstd_j mstd_q (A_jq - N mave_j mave_q): the second part is added here
+        if ((uint32_t)tid < ncarry) {
+            double v = p.carry[tid] + s1;
+            if constexpr (!MG) {
+                for (int q = 0; q < npend_in; ++q)
+                    v -= sh.pev[3 * q] * (mm.mstd * sh.pev[3 * q + 2] * (p.n_total * (mm.mave * sh.pev[3 * q + 1])));
             }
+            sh.dp[tid] = v;
         }
     }
     if (tid == 0) {
@@ -364,7 +385,8 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     // pending updates handed to the next launch: kept in LDS by thread 0 (sh.pvl is free again: the
     // streaming loop is over), markers in sh.pmk
     if (tid < MAX_SEG) sh.pmk[tid] = -1;
-    if (tid < 3 * MAX_SEG) sh.pvl[tid] = 0.0;
+    if (tid < 3 * MAX_SEG) sh.pvl[tid] = sh.pel[tid] = 0.0;
+    bool ev_miss = false; // an update handed on comes from a column with missing calls (uniform)
     int npend = 0;
     unsigned long long nnz_add = 0;
     int stop_seg = -1; // segment whose walk ended on an event with a non-zero update (the last pending one)
@@ -481,7 +503,11 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                     sh.pvl[3 * npend] = -(av * sd * db);
                     sh.pvl[3 * npend + 1] = db * (1.0 - av) * sd;
                     sh.pvl[3 * npend + 2] = db * (2.0 - av) * sd;
+                    sh.pel[3 * npend] = db;
+                    sh.pel[3 * npend + 1] = av;
+                    sh.pel[3 * npend + 2] = sd;
                 }
+                ev_miss = ev_miss || (sh.ada[sh.flags[F_FPOS]] & 2) != 0;
                 ++npend;
                 ++nnz_add;
                 stop_seg = seg;
@@ -498,26 +524,20 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     // ---- hand the state to the next launch ---------------------------------------
     const uint32_t naccept = sh.flags[F_NACC];
     const uint32_t pos = sh.flags[F_POS];
-    // Carried dots.  The walk ended on an event at batch position fpos with columns left behind it: their dots are
-    // stale only by that event's update (and, for later segments, by the earlier pivots' updates, for which the Gram
-    // terms are here).  Hand them on corrected for the pivots; the next launch takes the Gram term with the event's
-    // column instead of streaming them again.  Columns with missing calls (or such an event column) end the carry.
+    // Carried dots.  The walk ended on an event at batch position fpos with columns left behind it: their dots (sh.dp:
+    // against the residual this launch streamed, i.e. with its pending updates applied) are stale only by the updates of
+    // THIS launch's events, all of which are handed on as pending.  They go to the next launch as they are; it takes the
+    // integer Gram terms with its pending columns instead of streaming them again.  The one-term Gram identity needs both
+    // columns free of missing calls: in the builds without the four-term sums such a column, or such an event, ends the carry.
     uint32_t carry_next = 0u;
-    if constexpr (CARRY) {
+    {
         const uint32_t fpos = sh.flags[F_FPOS];
-        const bool can = carry_on && stop_seg >= 0 && sh.flags[F_STOP] != 0 && fpos + 1u < nb && !(sh.ada[fpos] & 2); // uniform
+        const bool can = carry_on && sh.flags[F_STOP] != 0 && fpos + 1u < nb && (MG || !ev_miss); // uniform
         if (can) {
-            const uint32_t bad = ((uint32_t)tid > fpos && (uint32_t)tid < nb && mm.miss) ? (uint32_t)tid : nb;
+            const uint32_t bad = (!MG && (uint32_t)tid > fpos && (uint32_t)tid < nb && mm.miss) ? (uint32_t)tid : nb;
             const uint32_t first_bad = block_min_u32(sh, bad, tid);
             carry_next = first_bad - (fpos + 1u);
-            if ((uint32_t)tid > fpos && (uint32_t)tid < first_bad) {
-                double v = sh.dp[tid];
-                for (int q = 0; q < stop_seg; ++q) { // the pivots already walked past, in order (same terms as the posterior's)
-                    const double A = sh.tot[NR * tid + NSUM + q];
-                    v += sh.ev[3 * q] * (mm.mstd * sh.ev[3 * q + 2] * (A - p.n_total * (mm.mave * sh.ev[3 * q + 1])));
-                }
-                p.carry[(uint32_t)tid - (fpos + 1u)] = v;
-            }
+            if ((uint32_t)tid > fpos && (uint32_t)tid < first_bad) p.carry[(uint32_t)tid - (fpos + 1u)] = sh.dp[tid];
         }
     }
     if (dbgp && tid == 0) dbgp[23] = wall_clock64(); // segments done
@@ -584,7 +604,10 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if (d.pend_marker[0] >= 0) n.cur = d.cur ^ 1u;
         for (int q = 0; q < MAX_SEG; ++q) {
             n.pend_marker[q] = sh.pmk[q];
-            for (int c = 0; c < 3; ++c) n.pv[q][c] = sh.pvl[3 * q + c];
+            for (int c = 0; c < 3; ++c) {
+                n.pv[q][c] = sh.pvl[3 * q + c];
+                n.pend_ev[q][c] = sh.pel[3 * q + c];
+            }
         }
         n.nnz += nnz_add;
         n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
@@ -595,7 +618,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         n.carry_n = carry_next;
         {
-            const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, nb, p.cols_per_group);
+            const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, sweep_groups(p, d, nb, MG));
             const uint32_t tiles = (ntg + S - 1) / S;
             n.streamed_sum += nb - ncarry;
             if (nb > ncarry) {
@@ -603,10 +626,7 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                 n.tiles_max = tiles > n.tiles_max ? tiles : n.tiles_max;
             }
         }
-        if (carry_next) {
-            for (int c = 0; c < 3; ++c) n.carry_ev[c] = sh.ev[3 * stop_seg + c];
-            n.carried_sum += carry_next;
-        }
+        n.carried_sum += carry_next;
         *p.desc = n;
         if (dbgp) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
             dbgp[4] = wall_clock64();
@@ -758,11 +778,39 @@ __device__ __forceinline__ bool p2p_exchange(const SweepParams& p, const DescHea
     return true;
 }
 
-// One launch of the sweep.  grid = (S, ceil(batch_limit/CPG)): blockIdx.y owns a
-// group of up to CPG batch columns, blockIdx.x a strided set of tile groups
-// (4 wave tiles = 4096 individuals each).  Every lane keeps the sums of its
-// columns in registers across all its tiles; one wave/block reduction per
-// launch, then per-slice partial rows for the last arriver.
+// 64-lane integer sum on the DPP path (the Gram partials): total returned wave-uniform
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); // row_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One launch of the sweep.  The batch is [carried columns | fresh columns]: the first `carry_n` columns were streamed by
+// the previous launch (they lay behind the event that ended it), their dots against THAT launch's residual are in
+// SweepParams::carry.  A 1-D grid of S * nactive workgroups; a group of S workgroups (slices: strided sets of tile
+// groups of 4096 individuals) is one of
+//   the update group   (one, when updates are pending) applies the pending updates of the previous launch's events to
+//                      eps and stores the other eps buffer -- nothing else, so that no other workgroup stores;
+//   Gram-only groups   CCG carried columns each: no eps, no LDS, only the integer Gram terms x_j'x_q with every pending
+//                      column q (the updates their dots do not contain yet) and with this launch's earlier pivots;
+//   fresh groups       CPG columns each: the pending updates on the eps tile in registers, then s1 = sum g nm eps (and
+//                      s2 for a column with missing calls), plus the Gram terms with this launch's earlier pivots.
+// Every lane keeps its sums in registers across all its tiles; column dwords are prefetched TWO tiles ahead (the count
+// of loads per tile is a compile-time constant, so the loop waits on vmcnt(loads of one tile) instead of vmcnt(0)); one
+// wave / block reduction per launch, per-slice partial rows, the last of a group's S workgroups sums them over the slices
+// (for carried columns: straight into G_j = sum_q dbeta_q mstd_j mstd_q A_jq), the last group runs the draw phase.
 // NOMISS: the data has no missing call in any column (known from the marker statistics): the second masked sum and its
 // reductions are compiled out (s2 is the sum of eps for every column).
 // DBG: stage timestamps (option debug_timing); the production builds carry none of it.
@@ -772,7 +820,11 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     unsigned long long* const dbgp = DBG ? p.dbg : nullptr;
     static_assert(!(MG && NOMISS), "the missing-call Gram build is for data with missing calls");
     static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
-    constexpr int NR = sweep_rows(SEG, MG); // rows per batch column: s1, s2 and the Gram terms
+    constexpr int NR = sweep_rows(SEG, MG);     // rows per batch column in `totals`: s1 (or G_j), s2, T per earlier pivot
+    constexpr int T = MG ? 4 : 1;               // integer sums per Gram term
+    constexpr int CCG = carried_cpg(MG);        // carried columns per Gram-only workgroup
+    constexpr int NRC = carried_rows(SEG, MG);  // rows a Gram-only group publishes per column: T per pending update, T per pivot
+    constexpr int RB = group_rows(CPG, SEG, MG); // row block of one group in `partials`
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
     const bool pend = d.pend_marker[0] >= 0;
@@ -788,28 +840,28 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t voff = (uint32_t)lane << 2; // the lane's dword inside a 256-byte column piece; bases stay wave-uniform
-    // 1-D grid of slices_max * groups_max workgroups; the ACTIVE ones are the first S * nactive
-    // in dispatch order (idle ones behind them leave at once and delay nobody)
-    const uint32_t nactive = (nb + CPG - 1) / CPG > 0 ? (nb + CPG - 1) / CPG : 1u;
-    // slices actually used: keep the active workgroups co-resident (3 per CU at this register
-    // budget; 2 at CPG = 16) -- a second wave of workgroups would double the streaming phase
-    // p.resident: co-resident workgroups of this build at this launch's LDS size (occupancy query on the host)
-    // Carried columns (the first ncarry of the batch: streamed by the previous launch, see SweepDesc::carry_n) skip the
-    // dot product and only take one integer Gram term.  Slices stay uniform: the compute units' VALUs are shared by the
-    // co-resident workgroups, so the cheap carried groups simply leave issue slots to the fresh ones (giving them fewer
-    // slices instead was measured: no difference).
-    constexpr bool CARRY = !MG;
-    const uint32_t ncarry = (CARRY && p.carry_on && p.gram && pend) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
-    const uint32_t S = sweep_slices(p, nb, CPG);
+    const uint32_t ncar = sweep_carried(p, d, nb);
+    const uint32_t nu = pend ? 1u : 0u, ncg = (ncar + CCG - 1) / CCG, nfg = (nb - ncar + CPG - 1) / CPG;
+    const uint32_t nactive = nu + ncg + nfg; // >= 1: pending updates or columns
+    // slices: the active workgroups (the first S * nactive in dispatch order; idle ones behind them leave at once) must be
+    // co-resident -- a second round of workgroups would double the streaming phase
+    const uint32_t S = sweep_slices(p, nactive);
     if (blockIdx.x >= S * nactive) return;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
-    const uint32_t c0 = group * CPG;
-    const uint32_t c1 = (c0 + CPG < nb) ? c0 + CPG : nb;
-    const uint32_t ncol = (c1 > c0) ? c1 - c0 : 0u;
-    const bool first_group = group == 0;
+    const int kind = group < nu ? 0 : (group < nu + ncg ? 1 : 2); // update / Gram-only / fresh
+    const uint32_t c0 = kind == 1 ? (group - nu) * CCG : ncar + (kind == 2 ? (group - nu - ncg) * CPG : 0u);
+    const uint32_t cend = kind == 1 ? ncar : nb;
+    const uint32_t c1 = kind == 0 ? c0 : ((c0 + (kind == 1 ? CCG : CPG) < cend) ? c0 + (kind == 1 ? CCG : CPG) : cend);
+    const uint32_t ncol = c1 - c0;
+    const uint32_t rows_per_col = kind == 1 ? NRC : NR;
     const double* eps_in = d.cur ? p.eps1 : p.eps0;
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
+    const uint32_t nt = slice < ntg ? (ntg - slice + S - 1) / S : 0u; // tile groups of this workgroup
+    auto tile_at = [&](uint32_t k) { // the k-th tile of this wave; past the end: the last one again (loads stay in range, results unused)
+        const uint32_t kk = k < nt ? k : (nt ? nt - 1 : 0u);
+        return (slice + kk * S) * BLOCK_WAVES + wave;
+    };
 
     if (pend && tid < 16 * SEG) { // entry (c1 << 2 | c0) of pending update q: the addends of two neighbouring individuals
         const int q = tid >> 4;
@@ -819,53 +871,241 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     }
     if (dbgp && blockIdx.x == 0 && tid == 0) dbgp[0] = wall_clock64();
     const unsigned long long t_entry = dbgp ? wall_clock64() : 0ull;
-
     unsigned long long t_loop = 0ull;
-    double a1[CPG], a2[CPG];
-    // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields
-    // (a lane adds at most 64 per tile; the host keeps tiles per lane below 1000): ag01 = pivot 0 | pivot 1 << 16
-    uint32_t ag01[CPG], ag2[CPG];
-#pragma unroll
-    for (int c = 0; c < CPG; ++c) {
-        a1[c] = a2[c] = 0.0;
-        ag01[c] = ag2[c] = 0u;
-    }
-    const uint8_t* colp[CPG];
-    bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
-    bool ccar[CPG];  // wave-uniform: carried column (its dot is known; only the Gram term with the last pending column is taken)
-    int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
-    int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
-#pragma unroll
-    for (int c = 0; c < CPG; ++c) {
-        const uint32_t j = (c0 + c < nb) ? c0 + c : (nb ? nb - 1 : 0);
-        const int marker = nb ? p.order[d.cursor + j] : 0;
-        cmiss[c] = (!NOMISS && nb) ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
-        ccar[c] = c0 + c < ncarry;
-        int sg = 0;
-#pragma unroll
-        for (int q = 0; q < SEG - 1; ++q) sg += (c0 + c < nb && c0 + c >= nbs[q]) ? 1 : 0;
-        cseg[c] = sg;
-        ng = sg > ng ? sg : ng;
-        colp[c] = p.bed + (size_t)marker * p.stride;
-    }
-    const bool any_gram = ng > 0;
-    const uint8_t* pivp[SEG - 1];
-#pragma unroll
-    for (int q = 0; q < SEG - 1; ++q)
-        pivp[q] = p.bed + (size_t)((q < ng && nbs[q] > 0) ? p.order[d.cursor + nbs[q] - 1] : 0) * p.stride;
+
     int npend = 0;
 #pragma unroll
     for (int q = 0; q < SEG; ++q) npend += d.pend_marker[q] >= 0 ? 1 : 0;
+    // columns a lane's loads go to when a slot is not in use: any valid column (the loads keep the per-tile count constant)
+    const uint8_t* const anyp = p.bed + (size_t)(pend ? d.pend_marker[0] : (nb ? p.order[d.cursor] : 0)) * p.stride;
     const uint8_t* pendp[SEG];
 #pragma unroll
-    for (int q = 0; q < SEG; ++q) pendp[q] = p.bed + (size_t)(q < npend ? d.pend_marker[q] : 0) * p.stride;
+    for (int q = 0; q < SEG; ++q) pendp[q] = q < npend ? p.bed + (size_t)d.pend_marker[q] * p.stride : anyp;
+    double* wbase = sh.wpart;       // per-wave partial rows of this workgroup: [BLOCK_WAVES][wstr]
+    uint32_t wstr = sh.wstride;
 
-    if (pend) __syncthreads(); // sh.pvt is staged
-    {
-        // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces --
-        // exactly the permuted eps layout) one tile ahead of the arithmetic; column dwords of the
-        // next tile are prefetched into registers.
+    // lane mask of valid slots for a tile that reaches into the padding behind the shard's last individual (data without
+    // missing calls holds the missing code only there: everywhere else a dword is used as loaded)
+    auto pad_keep = [&](uint32_t tile, bool& pad_tile) -> uint32_t {
+        pad_tile = NOMISS && (tile + 1u) * (uint32_t)TILE > p.n_local; // wave-uniform
+        if (!pad_tile) return 0xffffffffu;
+        const uint32_t i0 = tile * (uint32_t)TILE + ((uint32_t)lane << 4);
+        const uint32_t nv = i0 >= p.n_local ? 0u : (p.n_local - i0 >= 16u ? 16u : p.n_local - i0);
+        return nv >= 16u ? 0xffffffffu : ((1u << (2u * nv)) - 1u);
+    };
+
+    // draw-phase state every workgroup stages before its loop (any of them may turn out to be the last arriver)
+    auto stage_all = [&]() {
+        if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
+        if (!p.sums_out) stage_rng(p, sh, tid);
+        if (tid < 3 * MAX_SEG) sh.pev[tid] = pend ? p.desc->pend_ev[tid / 3][tid % 3] : 0.0;
+    };
+
+    if (kind == 0) {
+        // ---- the update group: eps_out = eps_in + pending updates, a8 (src/BayesRRm.cpp:1976-2010,2022,2471) ---------------
+        __syncthreads(); // sh.pvt is staged
         unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
+        uint32_t wp[SEG], wpn[SEG];
+        auto loads = [&](uint32_t tile, uint32_t (&dst)[SEG]) {
+            const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
+                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) dst[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tile << 8) + voff);
+        };
+        if (nt) loads(tile_at(0), wp);
+        stage_all();
+        for (uint32_t k = 0; k < nt; ++k) {
+            const uint32_t tile = tile_at(k);
+            wait_vmcnt<0>();
+            double e[IPT];
+            {
+                const double2* lp = reinterpret_cast<const double2*>(est) + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double2 v = lp[i * 64];
+                    e[2 * i] = v.x;
+                    e[2 * i + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // eps is in registers: the staging tile may be overwritten
+            if (k + 1 < nt) loads(tile_at(k + 1), wpn);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q)
+                if (q < npend) apply_update16_lds(wp[q], sh.pvt + 16 * q, e);
+            store_eps16(eps_out, tile, lane, e);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) wp[q] = wpn[q];
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        t_loop = dbgp ? wall_clock64() : 0ull;
+    } else if (kind == 1) {
+        // ---- a Gram-only group: integer Gram terms of CCG carried columns --------------------------------------------------
+        constexpr int NLG = CCG + SEG + (SEG - 1); // loads per tile
+        wbase = reinterpret_cast<double*>(sh.estage); // no eps tiles here: the staging region holds this group's wave partials
+        wstr = CCG * NRC;
+        const uint8_t* colp[CCG];
+        uint32_t segmask = 0u; // 2 bits per column: its segment = number of earlier pivots of THIS launch its dot is corrected for
+        int ng = 0;
+#pragma unroll
+        for (int c = 0; c < CCG; ++c) {
+            const bool live = c0 + c < c1;
+            colp[c] = live ? p.bed + (size_t)p.order[d.cursor + c0 + c] * p.stride : anyp;
+            int sg = 0;
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) sg += (live && c0 + c >= nbs[q]) ? 1 : 0;
+            segmask |= (uint32_t)sg << (2 * c);
+            ng = sg > ng ? sg : ng;
+        }
+        const uint8_t* pivp[SEG - 1];
+#pragma unroll
+        for (int q = 0; q < SEG - 1; ++q) pivp[q] = (q < ng && nbs[q] > 0) ? p.bed + (size_t)p.order[d.cursor + nbs[q] - 1] * p.stride : anyp;
+        uint32_t wA[NLG], wB[NLG], wC[NLG]; // three rotating register sets, as in the fresh groups
+        auto loads = [&](uint32_t tile, uint32_t (&dst)[NLG]) {
+            const size_t off = ((size_t)tile << 8) + voff;
+#pragma unroll
+            for (int c = 0; c < CCG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) dst[CCG + q] = *reinterpret_cast<const uint32_t*>(pendp[q] + off);
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) dst[CCG + SEG + q] = *reinterpret_cast<const uint32_t*>(pivp[q] + off);
+        };
+        // 16-bit fields (a lane adds at most 64 per tile and term; the host keeps tiles per lane below 1000)
+        constexpr int NF = NRC;                  // fields per column: T per pending update, then T per pivot
+        constexpr int NREG = (NF + 1) / 2;
+        uint32_t acc[CCG][NREG];
+#pragma unroll
+        for (int c = 0; c < CCG; ++c)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) acc[c][r] = 0u;
+        if (nt) {
+            loads(tile_at(0), wA);
+            loads(tile_at(1), wB);
+        }
+        stage_all();
+        auto body = [&](uint32_t k, uint32_t (&w)[NLG], uint32_t (&wfree)[NLG]) __attribute__((always_inline)) {
+            wait_vmcnt<NLG>(); // all but the most recent tile's loads have landed: w is complete
+            if (k + 1 < nt) loads(tile_at(k + 2), wfree);
+            bool pad_tile;
+            const uint32_t keep = pad_keep(tile_at(k), pad_tile);
+            auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
+                if constexpr (NOMISS) {
+                    gwd = pad_tile ? (wd & keep) : wd;
+                    nmd = 0x55555555u;
+                } else {
+                    code_weights(wd, gwd, nmd);
+                }
+            };
+            // the columns the terms are taken with: pending updates 0..npend-1, then this launch's pivots
+            GramPivot gq[SEG + SEG - 1];
+            uint32_t xq[SEG + SEG - 1], nmq[SEG + SEG - 1];
+#pragma unroll
+            for (int q = 0; q < SEG + SEG - 1; ++q) {
+                uint32_t gwq;
+                weights(w[CCG + q], gwq, nmq[q]);
+                gq[q] = gram_pivot(gwq);
+                xq[q] = MG ? gram_xform(gwq) : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < CCG; ++c) {
+                uint32_t gwc, nmc;
+                weights(w[c], gwc, nmc);
+                const uint32_t xc = gram_xform(gwc);
+                const int sg = (int)((segmask >> (2 * c)) & 3u);
+                [[maybe_unused]] const uint32_t nmc2 = nmc | (nmc << 1);
+#pragma unroll
+                for (int q = 0; q < SEG + SEG - 1; ++q) {
+                    const bool on = q < SEG ? q < npend : (q - SEG) < sg; // wave-uniform
+                    if (!on) continue;
+                    if constexpr (MG) {
+                        // A = sum gw_j gw_q, B = sum gw_j nm_q, C = sum nm_j gw_q, D = sum nm_j nm_q
+                        const uint32_t nmq2 = nmq[q] | (nmq[q] << 1);
+                        acc[c][2 * q] += gram16x(xc, gq[q]) | ((uint32_t)__popc(xc & nmq2) << 16);
+                        acc[c][2 * q + 1] += (uint32_t)__popc(nmc2 & xq[q]) | ((uint32_t)__popc(nmc & nmq[q]) << 16);
+                    } else {
+                        acc[c][q >> 1] += gram16x(xc, gq[q]) << (16 * (q & 1));
+                    }
+                }
+            }
+        };
+        for (uint32_t k = 0; k < nt; k += 3) {
+            body(k, wA, wC);
+            if (k + 1 < nt) body(k + 1, wB, wA);
+            if (k + 2 < nt) body(k + 2, wC, wB);
+        }
+        wait_vmcnt<0>();
+        __syncthreads(); // the staging region is free (nobody uses it in this group) and every wave is past its loads
+        t_loop = dbgp ? wall_clock64() : 0ull;
+        // one cross-lane reduction per launch and field in use (a term is in use when its pending update / pivot exists: wave-uniform);
+        // a lane holds at most 64 per tile and field, so with fewer than 16 tiles the two 16-bit fields of a register are summed
+        // over the 64 lanes together (64 * 64 * 15 < 2^16), else one by one
+        const bool packed = nt < 16u;
+#pragma unroll
+        for (int c = 0; c < CCG; ++c) {
+            const int sg = (int)((segmask >> (2 * c)) & 3u);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                // fields 2r, 2r + 1 belong to term (2r) / T and (2r + 1) / T
+                const int q0 = (2 * r) / T, q1 = (2 * r + 1) / T;
+                const bool on0 = q0 < SEG ? q0 < npend : (q0 - SEG) < sg, on1 = (2 * r + 1 < NF) && (q1 < SEG ? q1 < npend : (q1 - SEG) < sg);
+                uint32_t lo = 0u, hi = 0u;
+                if (on0 || on1) {
+                    if (packed) {
+                        const uint32_t v = wave_sum_u32(acc[c][r]);
+                        lo = v & 0xffffu;
+                        hi = v >> 16;
+                    } else {
+                        lo = on0 ? wave_sum_u32(acc[c][r] & 0xffffu) : 0u;
+                        hi = on1 ? wave_sum_u32(acc[c][r] >> 16) : 0u;
+                    }
+                }
+                if (lane == 0) { // exact: integers far below 2^53
+                    wbase[wave * wstr + NRC * c + 2 * r] = (double)lo;
+                    if (2 * r + 1 < NF) wbase[wave * wstr + NRC * c + 2 * r + 1] = (double)hi;
+                }
+            }
+        }
+    } else {
+        // ---- a fresh group: a4 (src/BayesRRm.cpp:1766-1809) of CPG columns against eps + pending updates --------------------
+        constexpr int NLF = CPG + (SEG - 1) + SEG; // loads per tile besides the eps tile's LDS-DMA
+        double a1[CPG], a2[CPG];
+        // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields:
+        // ag01 = pivot 0 | pivot 1 << 16, ag2 = pivot 2; with missing calls (MG): ag01 = A | B << 16, ag2 = C | D << 16
+        uint32_t ag01[CPG], ag2[CPG];
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            a1[c] = a2[c] = 0.0;
+            ag01[c] = ag2[c] = 0u;
+        }
+        const uint8_t* colp[CPG];
+        bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
+        int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
+        int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const bool live = c0 + c < c1;
+            const uint32_t j = live ? c0 + c : c1 - 1; // ncol >= 1 in a fresh group
+            colp[c] = p.bed + (size_t)p.order[d.cursor + j] * p.stride;
+            cmiss[c] = !NOMISS ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
+            int sg = 0;
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) sg += (live && c0 + c >= nbs[q]) ? 1 : 0;
+            cseg[c] = sg;
+            ng = sg > ng ? sg : ng;
+        }
+        const bool any_gram = ng > 0;
+        const uint8_t* pivp[SEG - 1];
+#pragma unroll
+        for (int q = 0; q < SEG - 1; ++q) pivp[q] = (q < ng && nbs[q] > 0) ? p.bed + (size_t)p.order[d.cursor + nbs[q] - 1] * p.stride : anyp;
+
+        if (pend) __syncthreads(); // sh.pvt is staged
+        // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces -- exactly the permuted
+        // eps layout) one tile ahead of the arithmetic; the column dwords two tiles ahead, in registers
+        unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
+        const uint32_t est_addr = lds_addr(est), pvt_addr = lds_addr(sh.pvt);
         auto dma_eps = [&](uint32_t tile) {
             const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
 #pragma unroll
@@ -873,62 +1113,42 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
                                                  (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
         };
-        uint32_t w[CPG], wn[CPG], wpiv[SEG - 1] = {}, wpivn[SEG - 1] = {}, wp[SEG] = {}, wpn[SEG] = {};
-        uint32_t tg = slice;
-        if (tg < ntg) {
-            const uint32_t tile = tg * BLOCK_WAVES + wave;
-            dma_eps(tile);
+        // three register sets of column dwords ([0, CPG) columns, then SEG - 1 pivots, then SEG pending columns) rotate through
+        // the roles "tile k" / "tile k + 1, in flight" / "free: receives tile k + 2" without a register copy (a copy would wait
+        // for the loads it moves): the loop body is instantiated once per role assignment
+        uint32_t wA[NLF], wB[NLF], wC[NLF];
+        // (plain loads: the compiler tracks them and places exact vmcnt waits in straight-line code; for the two sets that are in
+        // flight across the loop's back edge it falls back to vmcnt(0) at their first use, i.e. one body in three drains the
+        // loads of the tile after it -- loads the compiler does not see would avoid that, but a register copy the allocator
+        // may place at the back edge would then read a register whose load has not landed)
+        auto loads = [&](uint32_t tile, uint32_t (&dst)[NLF]) {
+            const size_t off = ((size_t)tile << 8) + voff;
 #pragma unroll
-            for (int c = 0; c < CPG; ++c) w[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tile << 8) + voff);
+            for (int c = 0; c < CPG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
 #pragma unroll
-            for (int q = 0; q < SEG - 1; ++q)
-                if (q < ng) wpiv[q] = *reinterpret_cast<const uint32_t*>(pivp[q] + ((size_t)tile << 8) + voff);
+            for (int q = 0; q < SEG - 1; ++q) dst[CPG + q] = *reinterpret_cast<const uint32_t*>(pivp[q] + off);
 #pragma unroll
-            for (int q = 0; q < SEG; ++q)
-                if (q < npend) wp[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tile << 8) + voff);
+            for (int q = 0; q < SEG; ++q) dst[CPG + SEG - 1 + q] = *reinterpret_cast<const uint32_t*>(pendp[q] + off);
+        };
+        if (nt) { // issue order: eps tile 0, columns of tile 0, columns of tile 1
+            dma_eps(tile_at(0));
+            loads(tile_at(0), wA);
+            loads(tile_at(1), wB);
         }
-        // latency-bound loads of the draw phase, issued by EVERY workgroup before the streaming loop (any of them may turn
-        // out to be the last arriver) -- but behind the first tile's loads, so that their load -> LDS round trips overlap
-        // with the column bytes' way from HBM instead of preceding it
-        if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
-        if (!p.sums_out) stage_rng(p, sh, tid);
-        for (; tg < ntg; tg += S) {
-            const uint32_t tile = tg * BLOCK_WAVES + wave;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this tile's DMA (and column dwords) have landed
+        // latency-bound loads of the draw phase, issued by EVERY workgroup before the streaming loop -- but behind the first
+        // tiles' loads, so that their load -> LDS round trips overlap with the column bytes' way from HBM
+        stage_all();
+        auto body = [&](uint32_t k, uint32_t (&w)[NLF], uint32_t (&wfree)[NLF]) __attribute__((always_inline)) {
+            const uint32_t tile = tile_at(k);
+            wait_vmcnt<NLF>(); // everything but the most recent tile's column loads has landed: eps tile k, columns of tile k
             double e[IPT];
-            {
-                const double2* lp = reinterpret_cast<const double2*>(est) + lane;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double2 v = lp[k * 64];
-                    e[2 * k] = v.x;
-                    e[2 * k + 1] = v.y;
-                }
+            lds_eps16(est_addr, lane, e);
+            if (k + 1 < nt) { // issue order: eps tile k + 1, columns of tile k + 2
+                dma_eps(tile_at(k + 1));
+                loads(tile_at(k + 2), wfree);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // eps is in registers: the staging tile may be overwritten
-            const uint32_t tgn = tg + S;
-            if (tgn < ntg) {
-                const uint32_t tilen = tgn * BLOCK_WAVES + wave;
-                dma_eps(tilen);
-#pragma unroll
-                for (int c = 0; c < CPG; ++c) wn[c] = *reinterpret_cast<const uint32_t*>(colp[c] + ((size_t)tilen << 8) + voff);
-#pragma unroll
-                for (int q = 0; q < SEG - 1; ++q)
-                    if (q < ng) wpivn[q] = *reinterpret_cast<const uint32_t*>(pivp[q] + ((size_t)tilen << 8) + voff);
-#pragma unroll
-                for (int q = 0; q < SEG; ++q)
-                    if (q < npend) wpn[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tilen << 8) + voff);
-            }
-            // weights of a column dword: the device code IS the weight; only missing calls (code 11) have to be cleared.
-            // Data without missing calls holds that code in the padding slots behind the shard's last individual only
-            // (at most one tile group): there the lane's mask of valid slots clears it, everywhere else the dword is used as loaded.
-            uint32_t keep = 0xffffffffu;
-            const bool pad_tile = NOMISS && (tile + 1u) * (uint32_t)TILE > p.n_local; // wave-uniform
-            if (pad_tile) {
-                const uint32_t i0 = tile * (uint32_t)TILE + ((uint32_t)lane << 4);
-                const uint32_t nv = i0 >= p.n_local ? 0u : (p.n_local - i0 >= 16u ? 16u : p.n_local - i0);
-                keep = nv >= 16u ? 0xffffffffu : ((1u << (2u * nv)) - 1u);
-            }
+            bool pad_tile;
+            const uint32_t keep = pad_keep(tile, pad_tile);
             auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
                 if constexpr (NOMISS) {
                     gwd = pad_tile ? (wd & keep) : wd;
@@ -945,38 +1165,25 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                 nmp[q] = 0u;
                 if (q < ng) {
                     uint32_t gwq;
-                    weights(wpiv[q], gwq, nmp[q]);
+                    weights(w[CPG + q], gwq, nmp[q]);
                     gpv[q] = gram_pivot(gwq);
                     if (MG && q == 0) xp0 = gram_xform(gwq);
                 }
             }
-            GramPivot gcar{0u, 0u}; // the LAST pending column: the event the carried dots are not yet corrected for
             if (pend) { // the previous launch's event(s), in order
 #pragma unroll
                 for (int q = 0; q < SEG; ++q)
-                    if (q < npend) apply_update16_lds(wp[q], sh.pvt + 16 * q, e);
-                if (first_group) store_eps16(eps_out, tile, lane, e);
-                if constexpr (CARRY) {
-                    if (ccar[0]) { // carried columns are a prefix of the batch: the group has one iff its first column is
-                        uint32_t wl = wp[0], gwl, nml;
-#pragma unroll
-                        for (int q = 1; q < SEG; ++q) wl = (q == npend - 1) ? wp[q] : wl;
-                        weights(wl, gwl, nml);
-                        gcar = gram_pivot(gwl);
-                    }
-                }
+                    if (q < npend) apply_update16_asm(w[CPG + SEG - 1 + q], pvt_addr + 256u * (uint32_t)q, e);
             }
             uint32_t gw[CPG], nm[CPG];
 #pragma unroll
             for (int c = 0; c < CPG; ++c) weights(w[c], gw[c], nm[c]);
-            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds
-            // its slots in increasing order
+            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds its slots in increasing order
             if constexpr (CPG % 4 == 0) {
 #pragma unroll
                 for (int c0g = 0; c0g < CPG; c0g += 4)
-                    if (!(CARRY && ccar[c0g + 3])) // a block of four carried columns has nothing to add (prefix: the last one decides)
-                        fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
-                                   std::make_integer_sequence<int, IPT>{});
+                    fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
+                               std::make_integer_sequence<int, IPT>{});
             } else {
 #pragma unroll
                 for (int s = 0; s < IPT; ++s) {
@@ -992,9 +1199,8 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                         for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
                     }
                 }
-                const bool need_x = cseg[c] > 0 || (CARRY && ccar[c]);
-                const uint32_t xc = need_x ? gram_xform(gw[c]) : 0u;
                 if (cseg[c] > 0) {
+                    const uint32_t xc = gram_xform(gw[c]);
                     uint32_t g = gram16x(xc, gpv[0]);
                     if constexpr (MG) {
                         // B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p: popcounts against masks replicated into both bits
@@ -1008,95 +1214,112 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
                     }
                     ag01[c] += g;
                 }
-                if constexpr (CARRY) {
-                    if (ccar[c]) ag2[c] += gram16x(xc, gcar) << 16;
-                }
             }
-            if (tgn < ntg) {
-#pragma unroll
-                for (int c = 0; c < CPG; ++c) w[c] = wn[c];
-#pragma unroll
-                for (int q = 0; q < SEG - 1; ++q) wpiv[q] = wpivn[q];
-#pragma unroll
-                for (int q = 0; q < SEG; ++q) wp[q] = wpn[q];
-            }
+        };
+        for (uint32_t k = 0; k < nt; k += 3) {
+            body(k, wA, wC);
+            if (k + 1 < nt) body(k + 1, wB, wA);
+            if (k + 2 < nt) body(k + 2, wC, wB);
         }
+        wait_vmcnt<0>();
         __syncthreads(); // every wave is done with its staging tile: the union region may be reused
         t_loop = dbgp ? wall_clock64() : 0ull;
         // one cross-lane reduction per launch
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
             const double t1 = wave_sum(a1[c]), t2 = NOMISS ? 0.0 : wave_sum(a2[c]);
-            // exact: integers far below 2^53
-            const double g0 = any_gram ? wave_sum((double)(ag01[c] & 0xffffu)) : 0.0;
-            const double g1 = (MG ? any_gram : ng > 1) ? wave_sum((double)(ag01[c] >> 16)) : 0.0;
-            const double g2 = (MG ? any_gram : ng > 2) ? wave_sum((double)(ag2[c] & 0xffffu)) : 0.0;
-            const double g3 = ((MG && any_gram) || (CARRY && ccar[0])) ? wave_sum((double)(ag2[c] >> 16)) : 0.0; // D, or the carry term
+            const uint32_t g0 = any_gram ? wave_sum_u32(ag01[c] & 0xffffu) : 0u;
+            const uint32_t g1 = (MG ? any_gram : ng > 1) ? wave_sum_u32(ag01[c] >> 16) : 0u;
+            const uint32_t g2 = (MG ? any_gram : ng > 2) ? wave_sum_u32(ag2[c] & 0xffffu) : 0u;
+            const uint32_t g3 = (MG && any_gram) ? wave_sum_u32(ag2[c] >> 16) : 0u;
             if (lane == 0) {
-                double* wp_ = sh.wpart + wave * sh.wstride + NR * c;
+                double* wp_ = wbase + wave * wstr + NR * c;
                 wp_[0] = t1;
                 wp_[1] = t2;
-                wp_[2] = g0;
+                if constexpr (SEG > 1) wp_[2] = (double)g0; // exact: integers far below 2^53
                 if constexpr (MG) {
-                    wp_[3] = g1;
-                    wp_[4] = g2;
-                    wp_[5] = g3;
+                    wp_[3] = (double)g1;
+                    wp_[4] = (double)g2;
+                    wp_[5] = (double)g3;
                 } else {
-                    if constexpr (SEG > 2) wp_[3] = g1;
-                    if constexpr (SEG > 3) wp_[4] = g2;
-                    wp_[NR - 1] = g3;
+                    if constexpr (SEG > 2) wp_[3] = (double)g1;
+                    if constexpr (SEG > 3) wp_[4] = (double)g2;
                 }
             }
         }
     }
     __syncthreads();
 
-    // block partial = waves 0..3 in order, published write-through (sc1)
-    {
-        const uint32_t nrow = NR * ncol;
-        for (uint32_t t = tid; t < nrow; t += BLOCK) {
-            double v = sh.wpart[t];
-            v += sh.wpart[sh.wstride + t];
-            v += sh.wpart[2 * sh.wstride + t];
-            v += sh.wpart[3 * sh.wstride + t];
-            __hip_atomic_store(p.partials + (size_t)slice * ROWS_CAP + (NR * c0 + t), v, HG_RLX_AGENT);
-        }
+    // block partial = waves 0..3 in order, published write-through (sc1); this group's row block starts at group * RB
+    const uint32_t rb = group * (uint32_t)RB;
+    const uint32_t nrowg = rows_per_col * ncol;
+    for (uint32_t t = tid; t < nrowg; t += BLOCK) {
+        double v = wbase[t];
+        v += wbase[wstr + t];
+        v += wbase[2 * wstr + t];
+        v += wbase[3 * wstr + t];
+        __hip_atomic_store(p.partials + (size_t)slice * PROWS_CAP + rb + t, v, HG_RLX_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (eps + partials)
+    wait_vmcnt<0>(); // every storing wave drains (eps + partials)
     __syncthreads();
     const unsigned long long t_drain = dbgp ? wall_clock64() : 0ull;
-    // Two-level hand-off.  First the S workgroups of one column group: the last of them to arrive sums
-    // that group's rows over the slices in fixed order -- threads 0..127 take slices 0..31 of row t,
-    // threads 128..255 slices 32..63 (all 32 loads in flight; partials is [slice][row], so the loads of
-    // one slice are coalesced), row total = (slices 0..31) + (slices 32..63) -- and publishes the totals.
-    // The reduction thus runs in all groups at once, behind the stragglers of the streaming phase.
+    // Two-level hand-off.  First the S workgroups of one group: the last of them to arrive sums that group's rows over the
+    // slices in fixed order -- threads 0..127 take slices 0..31 of row t, threads 128..255 slices 32..63 (all 32 loads in
+    // flight; partials is [slice][row], so the loads of one slice are coalesced), row total = (slices 0..31) + (slices
+    // 32..63) -- and publishes the totals.  The reduction thus runs in all groups at once, behind the stragglers of the
+    // streaming phase.
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.gticket + group, 1u, HG_RLX_AGENT);
         sh.flags[F_LAST] = (t == S - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (!sh.flags[F_LAST]) return;
-    {
-        const uint32_t nrowg = NR * ncol;
+    if (kind != 0) {
+        double* const gred = sh.tot; // rows of a Gram-only group, reduced over the slices, before they are folded per column
         const uint32_t half = tid >> 7, rl = tid & 127u;
         for (uint32_t rr0 = 0; rr0 < nrowg; rr0 += 128) {
             const uint32_t rr = rr0 + rl;
             const bool live = rr < nrowg;
-            const uint32_t r = NR * c0 + rr;
-            const double* col = p.partials + (size_t)(half * 32u) * ROWS_CAP + (live ? r : 0);
+            const double* col = p.partials + (size_t)(half * 32u) * PROWS_CAP + rb + (live ? rr : 0);
             double v[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = (live && half * 32u + u < S) ? __hip_atomic_load(col + (size_t)u * ROWS_CAP, HG_RLX_AGENT) : 0.0;
+            for (int u = 0; u < 32; ++u) v[u] = (live && half * 32u + u < S) ? __hip_atomic_load(col + (size_t)u * PROWS_CAP, HG_RLX_AGENT) : 0.0;
             double acc = 0.0;
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc += v[u];
             if (rr0) __syncthreads(); // previous round's exchange buffer is free again
             if (half == 1) sh.red[rl] = acc;
             __syncthreads();
-            if (live && half == 0) __hip_atomic_store(p.totals + r, acc + sh.red[rl], HG_RLX_AGENT);
+            if (live && half == 0) {
+                if (kind == 2) __hip_atomic_store(p.totals + NR * c0 + rr, acc + sh.red[rl], HG_RLX_AGENT);
+                else gred[rr] = acc + sh.red[rl];
+            }
+        }
+        if (kind == 1) {
+            // A carried column's dot lacks the pending updates: x_j'eps_now = carried_j + sum_q dbeta_q x_j'x_q with
+            // x_j'x_q = mstd_j mstd_q (A_jq - N mave_j mave_q) (no missing calls) or mstd_j mstd_q (A - m_q B - m_j C + m_j m_q D).
+            // This rank's part G_j = sum_q dbeta_q mstd_j mstd_q (integer sums over ITS individuals) goes into the column's
+            // s1 row: it adds over ranks like every other row; the draw phase adds the carried dot and the N mave mave part.
+            __syncthreads();
+            if ((uint32_t)tid < ncol) {
+                const uint32_t j = c0 + (uint32_t)tid;
+                const double mj = p.s_mave[d.cursor + j], sj = p.s_mstd[d.cursor + j];
+                const double* r = gred + NRC * tid;
+                double G = 0.0;
+                for (int q = 0; q < npend; ++q) {
+                    const double db = sh.pev[3 * q], mq = sh.pev[3 * q + 1], sq = sh.pev[3 * q + 2];
+                    double a;
+                    if constexpr (MG) a = ((r[4 * q] - mq * r[4 * q + 1]) - mj * r[4 * q + 2]) + (mj * mq) * r[4 * q + 3];
+                    else a = r[q];
+                    G += db * (sj * sq * a);
+                }
+                __hip_atomic_store(p.totals + NR * j, G, HG_RLX_AGENT);
+                __hip_atomic_store(p.totals + NR * j + 1, 0.0, HG_RLX_AGENT);
+                for (int f = 0; f < (SEG - 1) * T; ++f) __hip_atomic_store(p.totals + NR * j + NSUM + f, r[SEG * T + f], HG_RLX_AGENT);
+            }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
     __syncthreads();
     // then the groups: the last one to publish runs the draw phase
     if (tid == 0) {
@@ -1173,6 +1396,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     if ((nb2 == 0 && !pend) || d.error) return;
     stage_marker_meta(p, d, nb2, threadIdx.x, sh);
     stage_rng(p, sh, threadIdx.x);
+    if (threadIdx.x < 3 * MAX_SEG) sh.pev[threadIdx.x] = pend ? p.desc->pend_ev[threadIdx.x / 3][threadIdx.x % 3] : 0.0;
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
     __syncthreads();
     sweep_draw_phase<SEG, MG, 0>(p, d, nbs, sh);

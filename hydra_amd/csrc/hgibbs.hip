@@ -534,8 +534,8 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemcpy(h->zig + 515, HG_ZIG_EXP_Y, 257 * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc)));
     HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
-    HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_BATCH) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_GROUPS) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
     HIP_TRY(hipMalloc(&h->carry, (size_t)MAX_BATCH * sizeof(double)));
     HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
@@ -684,7 +684,7 @@ static int alloc_problem(hgibbs_ctx* h, uint32_t n_global, uint32_t n_local, uin
     HIP_TRY(hipMemsetAsync(h->acum, 0, (size_t)M * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->groups, 0, (size_t)M * sizeof(int32_t), h->stream));
     const uint32_t nblk_x = h->n_pad / BLOCK_IND;
-    HIP_TRY(hipMalloc(&h->partials, (size_t)ROWS_CAP * S_CAP * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->partials, (size_t)PROWS_CAP * S_CAP * sizeof(double)));
     if (ensure_scratch(h, (size_t)nblk_x * 4 + 4096)) return 1;
     h->eps_cur = 0;
     h->have_stats = false;
@@ -1179,7 +1179,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->adaV, adaV_host, (size_t)M, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_BATCH) * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t), h->stream));
     k_gather_meta<<<(M + 255) / 256, 256, 0, h->stream>>>(h->order, h->mave, h->mstd, h->beta, h->groups, h->adaV, h->counts, h->s_mave, h->s_mstd,
                                                        h->s_bold, h->s_ga, M);
     HIP_TRY(hipGetLastError());
@@ -1249,7 +1249,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.totals = h->totals;
     p.carry = h->carry;
     // the carry term is a 16-bit field per lane like the other Gram partials; a carried column group may run on a single slice
-    p.carry_on = (h->carry_on && h->gram && h->n_pad / BLOCK_IND <= 1000u) ? 1u : 0u;
+    p.carry_on = (h->carry_on && h->gram) ? 1u : 0u; // (its Gram terms are 16-bit fields like the pivots': p.gram falls to 0 where they could overflow)
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
@@ -1283,7 +1283,13 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const uint32_t ntg = h->n_pad / BLOCK_IND;
     const uint32_t S = std::min<uint32_t>(h->slices ? h->slices : S_CAP, ntg);
     p.slices_max = S;
-    const dim3 grid(S * ngroups);
+    // most groups a launch can have: the update group, Gram-only groups of carried columns, fresh groups (a batch is at most
+    // `batch` columns, split between the last two kinds)
+    const uint32_t ccg = (uint32_t)carried_cpg(mg ? 1 : 0);
+    const uint32_t groups_max = 1u + (batch + ccg - 1) / ccg + ngroups;
+    if (groups_max > (uint32_t)MAX_GROUPS || (uint64_t)groups_max * group_rows((int)cpg, tier, mg ? 1 : 0) > (uint64_t)PROWS_CAP)
+        return fail("hgibbs_sweep: %u groups of %d partial rows exceed the partial buffer", groups_max, group_rows((int)cpg, tier, mg ? 1 : 0));
+    const dim3 grid(S * groups_max);
     uint64_t total_launches = 0;
     // the build of the kernel this sweep runs
     void (*kern)(SweepParams) = nullptr;
@@ -1315,7 +1321,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     // min(slices, resident / groups) slices, so a lane sees at most ntg / that many tiles -- refuse the chain of
     // segments where that could overflow
     {
-        const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(S, p.resident / std::max<uint32_t>(1u, ngroups)));
+        const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(S, p.resident / std::max<uint32_t>(1u, groups_max)));
         if ((ntg + s_min - 1) / s_min > 1000u) p.gram = 0;
     }
     auto launch_one = [&]() { kern<<<grid, BLOCK, lds, h->stream>>>(p); };

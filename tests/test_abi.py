@@ -68,3 +68,22 @@ def test_cli_rejects_what_hydra_rejects(tmp_path):
                         "--mcmc-out-dir", str(tmp_path / "o"), "--mcmc-out-name", "t", "--number-markers", "6"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "opt.numberIndividuals is zero" in r.stderr
+
+
+def test_inline_assembly_lds_reads_are_not_touched_before_their_wait(tmp_path):
+    """The streaming loops read LDS from inline assembly (the compiler would otherwise drain every load in flight before an
+    LDS read it emits itself) and place the lgkmcnt wait by hand: in the device assembly of the library no instruction may
+    mention the destination registers of such a read before that wait (tools/asm_check.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "hgibbs.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-o", str(out), os.path.join(root, "hydra_amd", "csrc", "hgibbs.hip")], stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_check.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "violations: 0" in r.stdout and "checked: 0," not in r.stdout
