@@ -75,6 +75,7 @@ __host__ __device__ constexpr int group_rows(int cpg, int seg, int mg)
 constexpr int MAX_GROUPS = 1 + MAX_BATCH / 8 + MAX_BATCH / 2; // update group + Gram-only groups + fresh groups at their smallest sizes
 constexpr int PROWS_CAP = 10240;         // partial rows per slice: groups x group_rows of any build (checked on the host)
 constexpr int ROWS_CAP = NROW * MAX_BATCH + 8; // rows of `totals` (padded)
+constexpr int AHEAD_MAX = 256;           // most columns a launch streams ahead of its batch
 constexpr int MAX_RANKS = 16;             // GPUs of one node that can share the in-launch exchange
 constexpr int MT_BUF = 2 * MT_N;         // current + next MT19937 block staged in LDS
 
@@ -96,7 +97,8 @@ struct SweepDesc {
     // event that ended it); their dots against THIS launch's residual are in SweepParams::carry, and the next launch only
     // takes their integer Gram terms with its pending columns (this launch's events)
     uint32_t carry_n;
-    uint32_t pad_;
+    uint32_t carry_left;    // the first carry_left of them were left over by this launch's walk (dots in SweepParams::carry); the rest it
+                            // streamed ahead (raw sums in SweepParams::ahead_raw)
     double pend_ev[MAX_SEG][3]; // (dbeta, mave, mstd) of the pending updates: what the Gram correction of a carried dot needs
     uint64_t carried_sum;   // columns carried so far (statistics)
     uint64_t streamed_sum;  // batch columns whose dot was streamed (planned columns minus the carried ones), statistics
@@ -153,6 +155,11 @@ struct SweepParams {
     SweepDesc* desc;
     double* carry;         // [MAX_BATCH] dots of the carried columns (written by the draw phase, read by the next one)
     uint32_t carry_on;     // 1: launches may hand dots of already streamed columns to the next one
+    uint32_t ahead_cols;   // columns a launch streams ahead of its batch while its last workgroup draws (0: none)
+    double* ahead_raw;     // [2][AHEAD_MAX][2]: (s1, s2) of the columns streamed ahead, by launch parity
+    double* apartials;     // [S_CAP][2 * AHEAD_MAX]: their per-slice rows
+    uint32_t* aticket;     // [AHEAD_MAX / 2]: per ahead group, slices that have stored their rows
+    uint32_t* aqueue;      // [2]: next item of the ahead queue, by launch parity; [2]: go word (the number of the launch whose hand-off is over)
     double* partials;      // [S_CAP][PROWS_CAP]: per slice, one row block per group, written sc1
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals

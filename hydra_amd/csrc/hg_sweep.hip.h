@@ -29,7 +29,7 @@ struct LdsGen {
 // The few descriptor fields the streaming workgroups need (the whole SweepDesc in scalar
 // registers would crowd out the loop's pointers).
 struct DescHead {
-    uint32_t cursor, cur, rng_idx, error, carry_n;
+    uint32_t cursor, cur, rng_idx, error, carry_n, carry_left;
     unsigned long long seq;
     int32_t pend_marker[MAX_SEG];
     uint32_t seg_end[MAX_SEG];
@@ -44,6 +44,7 @@ __device__ __forceinline__ DescHead load_desc_head(const SweepDesc* g)
     d.error = g->error;
     d.seq = g->seq;
     d.carry_n = g->carry_n;
+    d.carry_left = g->carry_left;
 #pragma unroll
     for (int q = 0; q < MAX_SEG; ++q) {
         d.pend_marker[q] = g->pend_marker[q];
@@ -78,14 +79,12 @@ struct SweepShared {
     double* pvl;       // 3*MAX_SEG: update constants of the events this launch hands on (draw phase)
     double* pel;       // 3*MAX_SEG: (dbeta, mave, mstd) of the same events
     double* pev;       // 3*MAX_SEG: (dbeta, mave, mstd) of the PENDING updates of this launch (staged from the descriptor)
-    double2* pvt;      // [MAX_SEG][16]: the pending updates as a table over a PAIR of 2-bit codes (see apply_update16_lds); shares
-                       // its 1 KiB with `red` (the table is dead once the streaming loop is over)
+    double2* pvt;      // [MAX_SEG][16]: the pending updates as a table over a PAIR of 2-bit codes (see apply_update16_lds)
     int32_t* pmk;      // MAX_SEG: markers of the events this launch hands on
     uint8_t* scanf;    // 2*BLOCK flag bytes of the sweep positions after the cursor (bit 0 predicted event, bit 1 missing calls)
     uint32_t wstride;  // NROW*cpg + 1
     uint32_t bcap;     // batch capacity of this launch
 };
-static_assert(MAX_SEG * 16 * 16 <= 128 * 8, "the update table shares the exchange buffer");
 enum { F_LAST = 0, F_POS = 1, F_P2PTMO = 2, F_NACC = 3, F_STOP = 4, F_FPOS = 5, F_FMARK = 6, F_ERR = 7 };
 
 constexpr size_t EPS_STAGE_BYTES = (size_t)BLOCK_WAVES * TILE * sizeof(double); // one wave tile of eps per wave (LDS-DMA target)
@@ -109,7 +108,7 @@ __host__ __device__ inline size_t sweep_lds_meta_bytes(uint32_t bcap)
 __host__ __device__ inline size_t sweep_lds_fixed_bytes(uint32_t cpg, int nr, uint32_t bcap)
 {
     size_t n = sweep_lds_meta_bytes(bcap);
-    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + 128 * 8 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * 3 * MAX_SEG * 8 + 16;
+    n += MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + MAX_SEG * 16 * 16 + 16 * 8 + 32 + 16 + 2 * BLOCK + 3 * 3 * MAX_SEG * 8 + 16;
     n += (size_t)BLOCK_WAVES * (nr * cpg + 1) * 8;
     return (n + 15) & ~(size_t)15;
 }
@@ -130,8 +129,14 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
-    sh.red = reinterpret_cast<double*>(q);
-    sh.pvt = reinterpret_cast<double2*>(q); q += 128 * 8; // MAX_SEG * 16 * 16 bytes: the streaming loop's table, then the tail's exchange buffer
+    sh.pvt = reinterpret_cast<double2*>(q); q += MAX_SEG * 16 * 16; // the pending updates as tables over a pair of codes: live for the whole
+                                                                   // launch (the ahead phase streams with them after the hand-off)
+    // the exchange buffer of the group-stage reductions (1 KiB) lies on the SECOND generator block: that one is written only by
+    // the draw phase (mt_next_block), after the drawing workgroup's own group stage.  The carve-up must stay within a third of
+    // a compute unit's LDS in the hardware's allocation granules (3 x 42 x 1280 B): 32 bytes more once cost a second round
+    // of workgroups, +10 us per launch
+    sh.red = reinterpret_cast<double*>(sh.mt + MT_N);
+    static_assert((MT_BUF - MT_N) * 4 >= 128 * 8 && (MT_N * 4) % 8 == 0, "the exchange buffer fits the second generator block");
     sh.ev = reinterpret_cast<double*>(q); q += 16 * 8;
     sh.flags = reinterpret_cast<uint32_t*>(q); q += 32;
     sh.red_u = reinterpret_cast<uint32_t*>(q); q += 16;
@@ -237,6 +242,24 @@ __device__ __forceinline__ uint32_t sweep_carried(const SweepParams& p, const De
     return (p.carry_on && p.gram && d.pend_marker[0] >= 0) ? (d.carry_n < nb ? d.carry_n : nb) : 0u;
 }
 
+// Columns a launch streams AHEAD: while the last-arriving workgroup draws, the others take the columns that follow the batch
+// from a queue (dots against this launch's residual, exactly like its fresh columns); the next launch finds them as carried
+// columns behind the ones this launch left over.  In the builds that carry on the one-term Gram identity a column with
+// missing calls ends the range.  flags: the staged scan flags (bit 1: missing calls) of the positions after the cursor.
+template <int MG, int NOMISS>
+__device__ __forceinline__ uint32_t sweep_ahead_cols(const SweepParams& p, const DescHead& d, uint32_t nb, const SweepShared& sh, int tid)
+{
+    const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
+    uint32_t n = (p.ahead_cols && p.carry_on && p.gram && !p.sums_out && remaining > nb) ? remaining - nb : 0u;
+    n = n < p.ahead_cols ? n : p.ahead_cols;
+    n = nb + n > 2u * BLOCK ? 2u * BLOCK - nb : n; // the flags are staged for 2 * BLOCK positions
+    if (MG || NOMISS || n == 0u) return n;
+    uint32_t bad = n;
+    for (uint32_t a = (uint32_t)tid; a < n; a += BLOCK)
+        if ((sh.scanf[nb + a] & 2u) && a < bad) bad = a;
+    return block_min_u32(sh, bad, tid);
+}
+
 // groups of a launch: the update group (when updates are pending), Gram-only groups of the carried columns, fresh groups
 __device__ __forceinline__ uint32_t sweep_groups(const SweepParams& p, const DescHead& d, uint32_t nb, int mg)
 {
@@ -324,7 +347,7 @@ __device__ __forceinline__ void posterior_items(const SweepParams& p, const Swee
 // with A_jq = sum_i gw_j gw_q the integer Gram term accumulated by the streaming loop.
 // Runs in ONE workgroup of 256 threads.
 // a5-a7: src/BayesRRm.cpp:1721-1723,1744-1753,1855-1921; dense dot algebra :1785-1790,1809.
-template <int SEG, int MG, int DBG>
+template <int SEG, int MG, int NOMISS, int DBG>
 __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const DescHead& d, const uint32_t (&nbs)[SEG],
                                                  const SweepShared& sh)
 {
@@ -365,8 +388,10 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         // a carried column: the dot the previous launch handed on (against ITS residual) plus sum_q dbeta_q x_j'x_q over the
         // updates applied since.  Row 0 holds G_j = sum_q dbeta_q mstd_j mstd_q A_jq (integer Gram terms, summed over ranks);
         // without missing calls x_j'x_q = mstd_j mstd_q (A_jq - N mave_j mave_q): the second part is added here
+        // (a column the previous launch streamed ahead has no finished dot: its raw sums went into row 0 as well, and without
+        // missing calls its s2 is the sum of eps, added here once for all ranks)
         if ((uint32_t)tid < ncarry) {
-            double v = p.carry[tid] + s1;
+            double v = ((uint32_t)tid < d.carry_left ? p.carry[tid] : (mm.miss ? 0.0 : -(mm.mstd * (mm.mave * p.eps_sum)))) + s1;
             if constexpr (!MG) {
                 for (int q = 0; q < npend_in; ++q)
                     v -= sh.pev[3 * q] * (mm.mstd * sh.pev[3 * q + 2] * (p.n_total * (mm.mave * sh.pev[3 * q + 1])));
@@ -529,16 +554,24 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
     // THIS launch's events, all of which are handed on as pending.  They go to the next launch as they are; it takes the
     // integer Gram terms with its pending columns instead of streaming them again.  The one-term Gram identity needs both
     // columns free of missing calls: in the builds without the four-term sums such a column, or such an event, ends the carry.
-    uint32_t carry_next = 0u;
+    // Behind them follow the columns this launch streams AHEAD while this phase runs (sweep_ahead_cols): usable by the next
+    // launch when the carried run reaches the end of the batch (or nothing is left over).
+    const uint32_t n_ahead = sweep_ahead_cols<MG, NOMISS>(p, d, nb, sh, tid);
+    uint32_t carry_next = 0u, carry_left = 0u;
     {
         const uint32_t fpos = sh.flags[F_FPOS];
-        const bool can = carry_on && sh.flags[F_STOP] != 0 && fpos + 1u < nb && (MG || !ev_miss); // uniform
-        if (can) {
+        const bool usable = carry_on && (MG || !ev_miss);                                 // uniform
+        const bool left = sh.flags[F_STOP] != 0 && fpos + 1u < nb;                          // columns lie behind the event that ended the walk
+        bool reach_end = true;
+        if (usable && left) {
             const uint32_t bad = (!MG && (uint32_t)tid > fpos && (uint32_t)tid < nb && mm.miss) ? (uint32_t)tid : nb;
             const uint32_t first_bad = block_min_u32(sh, bad, tid);
-            carry_next = first_bad - (fpos + 1u);
+            carry_left = first_bad - (fpos + 1u);
+            reach_end = first_bad == nb;
             if ((uint32_t)tid > fpos && (uint32_t)tid < first_bad) p.carry[(uint32_t)tid - (fpos + 1u)] = sh.dp[tid];
         }
+        carry_next = usable ? carry_left + (reach_end ? n_ahead : 0u) : 0u;
+        if (!usable) carry_left = 0u;
     }
     if (dbgp && tid == 0) dbgp[23] = wall_clock64(); // segments done
     // ---- plan of the next launch (positions relative to the NEW cursor), by wave 0 ------------
@@ -617,10 +650,11 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         n.carry_n = carry_next;
+        n.carry_left = carry_left;
         {
             const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, sweep_groups(p, d, nb, MG));
             const uint32_t tiles = (ntg + S - 1) / S;
-            n.streamed_sum += nb - ncarry;
+            n.streamed_sum += nb - ncarry + n_ahead;
             if (nb > ncarry) {
                 n.tiles_min = tiles < n.tiles_min ? tiles : n.tiles_min;
                 n.tiles_max = tiles > n.tiles_max ? tiles : n.tiles_max;
@@ -847,21 +881,27 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     // co-resident -- a second round of workgroups would double the streaming phase
     const uint32_t S = sweep_slices(p, nactive);
     if (blockIdx.x >= S * nactive) return;
-    const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
-    const int kind = group < nu ? 0 : (group < nu + ncg ? 1 : 2); // update / Gram-only / fresh
-    const uint32_t c0 = kind == 1 ? (group - nu) * CCG : ncar + (kind == 2 ? (group - nu - ncg) * CPG : 0u);
+    const uint32_t group = blockIdx.x / S;
+    // the work item of this workgroup: first its part of the batch (slice `slice` of group `group`), then -- behind the hand-off,
+    // while the last arriver draws -- items of the ahead queue (a fresh group of columns behind the batch, `ahead` set)
+    uint32_t slice = blockIdx.x % S, Sw = S; // slice of Sw of the current item
+    int kind = group < nu ? 0 : (group < nu + ncg ? 1 : 2); // update / Gram-only / fresh
+    uint32_t c0 = kind == 1 ? (group - nu) * CCG : ncar + (kind == 2 ? (group - nu - ncg) * CPG : 0u);
     const uint32_t cend = kind == 1 ? ncar : nb;
-    const uint32_t c1 = kind == 0 ? c0 : ((c0 + (kind == 1 ? CCG : CPG) < cend) ? c0 + (kind == 1 ? CCG : CPG) : cend);
-    const uint32_t ncol = c1 - c0;
+    uint32_t c1 = kind == 0 ? c0 : ((c0 + (kind == 1 ? CCG : CPG) < cend) ? c0 + (kind == 1 ? CCG : CPG) : cend);
+    uint32_t ncol = c1 - c0;
     const uint32_t rows_per_col = kind == 1 ? NRC : NR;
     const double* eps_in = d.cur ? p.eps1 : p.eps0;
     double* eps_out = d.cur ? p.eps0 : p.eps1;
     const uint32_t ntg = p.n_pad / BLOCK_IND; // tile groups
-    const uint32_t nt = slice < ntg ? (ntg - slice + S - 1) / S : 0u; // tile groups of this workgroup
+    uint32_t nt = slice < ntg ? (ntg - slice + Sw - 1) / Sw : 0u; // tile groups of the current item
     auto tile_at = [&](uint32_t k) { // the k-th tile of this wave; past the end: the last one again (loads stay in range, results unused)
         const uint32_t kk = k < nt ? k : (nt ? nt - 1 : 0u);
-        return (slice + kk * S) * BLOCK_WAVES + wave;
+        return (slice + kk * Sw) * BLOCK_WAVES + wave;
     };
+    uint32_t n_ahead = 0u, a_slices = 1u, a_groups = 0u; // ahead range of this launch (items of its queue: a group of columns x a slice)
+    const uint32_t apar = (uint32_t)(d.seq & 1ull);                    // this launch's half of the ahead buffers and queue counters
+    __builtin_amdgcn_s_setprio(2);
 
     if (pend && tid < 16 * SEG) { // entry (c1 << 2 | c0) of pending update q: the addends of two neighbouring individuals
         const int q = tid >> 4;
@@ -899,6 +939,190 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         if (!p.sums_out) stage_marker_meta(p, d, nb, tid, sh);
         if (!p.sums_out) stage_rng(p, sh, tid);
         if (tid < 3 * MAX_SEG) sh.pev[tid] = pend ? p.desc->pend_ev[tid / 3][tid % 3] : 0.0;
+    };
+
+    // ---- a fresh group: a4 (src/BayesRRm.cpp:1766-1809) of CPG columns [c0, c1) (batch positions) against eps + pending updates,
+    // slice `slice` of Sw; instantiated for the batch's own groups and, without the Gram terms, for the items of the ahead queue
+    auto fresh_item = [&](auto ahead_tag) __attribute__((always_inline)) {
+        constexpr bool AHEAD = decltype(ahead_tag)::value;
+        constexpr int NPV = AHEAD ? 0 : SEG - 1;  // pivot columns loaded per tile (an ahead item takes plain dots)
+        constexpr int NLF = CPG + NPV + SEG;      // loads per tile besides the eps tile's LDS-DMA
+        double a1[CPG], a2[CPG];
+        // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields:
+        // ag01 = pivot 0 | pivot 1 << 16, ag2 = pivot 2; with missing calls (MG): ag01 = A | B << 16, ag2 = C | D << 16
+        uint32_t ag01[CPG], ag2[CPG];
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            a1[c] = a2[c] = 0.0;
+            ag01[c] = ag2[c] = 0u;
+        }
+        const uint8_t* colp[CPG];
+        bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
+        int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
+        int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const bool live = c0 + c < c1;
+            const uint32_t j = live ? c0 + c : c1 - 1; // ncol >= 1 in a fresh group
+            colp[c] = p.bed + (size_t)p.order[d.cursor + j] * p.stride;
+            cmiss[c] = !NOMISS ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
+            int sg = 0;
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) sg += (!AHEAD && live && c0 + c >= nbs[q]) ? 1 : 0;
+            cseg[c] = sg;
+            ng = sg > ng ? sg : ng;
+        }
+        const bool any_gram = ng > 0;
+        const uint8_t* pivp[SEG - 1];
+#pragma unroll
+        for (int q = 0; q < SEG - 1; ++q) pivp[q] = (q < ng && nbs[q] > 0) ? p.bed + (size_t)p.order[d.cursor + nbs[q] - 1] * p.stride : anyp;
+
+        __syncthreads(); // sh.pvt is staged; an ahead item: the previous item's LDS reads are over
+        // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces -- exactly the permuted
+        // eps layout) one tile ahead of the arithmetic; the column dwords two tiles ahead, in registers
+        unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
+        const uint32_t est_addr = lds_addr(est), pvt_addr = lds_addr(sh.pvt);
+        auto dma_eps = [&](uint32_t tile) {
+            const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
+                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
+        };
+        // three register sets of column dwords ([0, CPG) columns, then SEG - 1 pivots, then SEG pending columns) rotate through
+        // the roles "tile k" / "tile k + 1, in flight" / "free: receives tile k + 2" without a register copy (a copy would wait
+        // for the loads it moves): the loop body is instantiated once per role assignment
+        uint32_t wA[NLF], wB[NLF], wC[NLF];
+        // (plain loads: the compiler tracks them and places exact vmcnt waits in straight-line code; for the two sets that are in
+        // flight across the loop's back edge it falls back to vmcnt(0) at their first use, i.e. one body in three drains the
+        // loads of the tile after it -- loads the compiler does not see would avoid that, but a register copy the allocator
+        // may place at the back edge would then read a register whose load has not landed)
+        auto loads = [&](uint32_t tile, uint32_t (&dst)[NLF]) {
+            const size_t off = ((size_t)tile << 8) + voff;
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
+#pragma unroll
+            for (int q = 0; q < NPV; ++q) dst[CPG + q] = *reinterpret_cast<const uint32_t*>(pivp[q] + off);
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) dst[CPG + NPV + q] = *reinterpret_cast<const uint32_t*>(pendp[q] + off);
+        };
+        if (nt) { // issue order: eps tile 0, columns of tile 0, columns of tile 1
+            dma_eps(tile_at(0));
+            loads(tile_at(0), wA);
+            loads(tile_at(1), wB);
+        }
+        // latency-bound loads of the draw phase, issued by EVERY workgroup before the streaming loop -- but behind the first
+        // tiles' loads, so that their load -> LDS round trips overlap with the column bytes' way from HBM
+        if (!AHEAD) stage_all();
+        auto body = [&](uint32_t k, uint32_t (&w)[NLF], uint32_t (&wfree)[NLF]) __attribute__((always_inline)) {
+            const uint32_t tile = tile_at(k);
+            wait_vmcnt<NLF>(); // everything but the most recent tile's column loads has landed: eps tile k, columns of tile k
+            double e[IPT];
+            lds_eps16(est_addr, lane, e);
+            if (k + 1 < nt) { // issue order: eps tile k + 1, columns of tile k + 2
+                dma_eps(tile_at(k + 1));
+                loads(tile_at(k + 2), wfree);
+            }
+            bool pad_tile;
+            const uint32_t keep = pad_keep(tile, pad_tile);
+            auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
+                if constexpr (NOMISS) {
+                    gwd = pad_tile ? (wd & keep) : wd;
+                    nmd = 0x55555555u;
+                } else {
+                    code_weights(wd, gwd, nmd);
+                }
+            };
+            GramPivot gpv[SEG - 1];
+            uint32_t nmp[SEG - 1], xp0 = 0u; // MG: non-missing mask of the pivot, x form of pivot 0
+#pragma unroll
+            for (int q = 0; q < SEG - 1; ++q) {
+                gpv[q] = GramPivot{0u, 0u};
+                nmp[q] = 0u;
+                if (!AHEAD && q < ng) {
+                    uint32_t gwq;
+                    weights(w[CPG + (AHEAD ? 0 : q)], gwq, nmp[q]);
+                    gpv[q] = gram_pivot(gwq);
+                    if (MG && q == 0) xp0 = gram_xform(gwq);
+                }
+            }
+            if (pend) { // the previous launch's event(s), in order
+#pragma unroll
+                for (int q = 0; q < SEG; ++q)
+                    if (q < npend) apply_update16_asm(w[CPG + NPV + q], pvt_addr + 256u * (uint32_t)q, e);
+            }
+            uint32_t gw[CPG], nm[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) weights(w[c], gw[c], nm[c]);
+            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds its slots in increasing order
+            if constexpr (CPG % 4 == 0) {
+#pragma unroll
+                for (int c0g = 0; c0g < CPG; c0g += 4)
+                    fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
+                               std::make_integer_sequence<int, IPT>{});
+            } else {
+#pragma unroll
+                for (int s = 0; s < IPT; ++s) {
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) a1[c] = __builtin_fma((double)((gw[c] >> (2 * s)) & 3u), e[s], a1[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                if constexpr (!NOMISS) {
+                    if (cmiss[c]) {
+#pragma unroll
+                        for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
+                    }
+                }
+                if (!AHEAD && cseg[c] > 0) {
+                    const uint32_t xc = gram_xform(gw[c]);
+                    uint32_t g = gram16x(xc, gpv[0]);
+                    if constexpr (MG) {
+                        // B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p: popcounts against masks replicated into both bits
+                        const uint32_t nmp2 = nmp[0] | (nmp[0] << 1), nmj2 = nm[c] | (nm[c] << 1);
+                        g |= (uint32_t)__popc(xc & nmp2) << 16;
+                        ag2[c] += (uint32_t)__popc(nmj2 & xp0) | ((uint32_t)__popc(nm[c] & nmp[0]) << 16);
+                    }
+                    if constexpr (SEG > 2) {
+                        if (cseg[c] > 1) g |= gram16x(xc, gpv[1]) << 16;
+                        if (cseg[c] > 2) ag2[c] += gram16x(xc, gpv[SEG > 3 ? 2 : 0]);
+                    }
+                    ag01[c] += g;
+                }
+            }
+        };
+        for (uint32_t k = 0; k < nt; k += 3) {
+            body(k, wA, wC);
+            if (k + 1 < nt) body(k + 1, wB, wA);
+            if (k + 2 < nt) body(k + 2, wC, wB);
+        }
+        wait_vmcnt<0>();
+        __syncthreads(); // every wave is done with its staging tile: the union region may be reused
+        t_loop = dbgp ? wall_clock64() : 0ull;
+        // one cross-lane reduction per launch
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const double t1 = wave_sum(a1[c]), t2 = NOMISS ? 0.0 : wave_sum(a2[c]);
+            const uint32_t g0 = any_gram ? wave_sum_u32(ag01[c] & 0xffffu) : 0u;
+            const uint32_t g1 = (MG ? any_gram : ng > 1) ? wave_sum_u32(ag01[c] >> 16) : 0u;
+            const uint32_t g2 = (MG ? any_gram : ng > 2) ? wave_sum_u32(ag2[c] & 0xffffu) : 0u;
+            const uint32_t g3 = (MG && any_gram) ? wave_sum_u32(ag2[c] >> 16) : 0u;
+            if (lane == 0) {
+                double* wp_ = wbase + wave * wstr + NR * c;
+                wp_[0] = t1;
+                wp_[1] = t2;
+                if constexpr (SEG > 1) wp_[2] = (double)g0; // exact: integers far below 2^53
+                if constexpr (MG) {
+                    wp_[3] = (double)g1;
+                    wp_[4] = (double)g2;
+                    wp_[5] = (double)g3;
+                } else {
+                    if constexpr (SEG > 2) wp_[3] = (double)g1;
+                    if constexpr (SEG > 3) wp_[4] = (double)g2;
+                }
+            }
+        }
     };
 
     if (kind == 0) {
@@ -1069,187 +1293,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             }
         }
     } else {
-        // ---- a fresh group: a4 (src/BayesRRm.cpp:1766-1809) of CPG columns against eps + pending updates --------------------
-        constexpr int NLF = CPG + (SEG - 1) + SEG; // loads per tile besides the eps tile's LDS-DMA
-        double a1[CPG], a2[CPG];
-        // integer Gram partials of a column of segment s with the pivots of segments 0..s-1, as 16-bit fields:
-        // ag01 = pivot 0 | pivot 1 << 16, ag2 = pivot 2; with missing calls (MG): ag01 = A | B << 16, ag2 = C | D << 16
-        uint32_t ag01[CPG], ag2[CPG];
-#pragma unroll
-        for (int c = 0; c < CPG; ++c) {
-            a1[c] = a2[c] = 0.0;
-            ag01[c] = ag2[c] = 0u;
-        }
-        const uint8_t* colp[CPG];
-        bool cmiss[CPG]; // wave-uniform: column has missing calls -> needs its own s2
-        int cseg[CPG];   // wave-uniform: segment of the column = number of earlier pivots its dot is corrected for
-        int ng = 0;      // Gram terms this workgroup needs (segment of its last live column)
-#pragma unroll
-        for (int c = 0; c < CPG; ++c) {
-            const bool live = c0 + c < c1;
-            const uint32_t j = live ? c0 + c : c1 - 1; // ncol >= 1 in a fresh group
-            colp[c] = p.bed + (size_t)p.order[d.cursor + j] * p.stride;
-            cmiss[c] = !NOMISS ? ((p.s_ga[d.cursor + j] & 0x20000000) != 0) : false;
-            int sg = 0;
-#pragma unroll
-            for (int q = 0; q < SEG - 1; ++q) sg += (live && c0 + c >= nbs[q]) ? 1 : 0;
-            cseg[c] = sg;
-            ng = sg > ng ? sg : ng;
-        }
-        const bool any_gram = ng > 0;
-        const uint8_t* pivp[SEG - 1];
-#pragma unroll
-        for (int q = 0; q < SEG - 1; ++q) pivp[q] = (q < ng && nbs[q] > 0) ? p.bed + (size_t)p.order[d.cursor + nbs[q] - 1] * p.stride : anyp;
-
-        if (pend) __syncthreads(); // sh.pvt is staged
-        // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces -- exactly the permuted
-        // eps layout) one tile ahead of the arithmetic; the column dwords two tiles ahead, in registers
-        unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
-        const uint32_t est_addr = lds_addr(est), pvt_addr = lds_addr(sh.pvt);
-        auto dma_eps = [&](uint32_t tile) {
-            const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
-                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
-        };
-        // three register sets of column dwords ([0, CPG) columns, then SEG - 1 pivots, then SEG pending columns) rotate through
-        // the roles "tile k" / "tile k + 1, in flight" / "free: receives tile k + 2" without a register copy (a copy would wait
-        // for the loads it moves): the loop body is instantiated once per role assignment
-        uint32_t wA[NLF], wB[NLF], wC[NLF];
-        // (plain loads: the compiler tracks them and places exact vmcnt waits in straight-line code; for the two sets that are in
-        // flight across the loop's back edge it falls back to vmcnt(0) at their first use, i.e. one body in three drains the
-        // loads of the tile after it -- loads the compiler does not see would avoid that, but a register copy the allocator
-        // may place at the back edge would then read a register whose load has not landed)
-        auto loads = [&](uint32_t tile, uint32_t (&dst)[NLF]) {
-            const size_t off = ((size_t)tile << 8) + voff;
-#pragma unroll
-            for (int c = 0; c < CPG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
-#pragma unroll
-            for (int q = 0; q < SEG - 1; ++q) dst[CPG + q] = *reinterpret_cast<const uint32_t*>(pivp[q] + off);
-#pragma unroll
-            for (int q = 0; q < SEG; ++q) dst[CPG + SEG - 1 + q] = *reinterpret_cast<const uint32_t*>(pendp[q] + off);
-        };
-        if (nt) { // issue order: eps tile 0, columns of tile 0, columns of tile 1
-            dma_eps(tile_at(0));
-            loads(tile_at(0), wA);
-            loads(tile_at(1), wB);
-        }
-        // latency-bound loads of the draw phase, issued by EVERY workgroup before the streaming loop -- but behind the first
-        // tiles' loads, so that their load -> LDS round trips overlap with the column bytes' way from HBM
-        stage_all();
-        auto body = [&](uint32_t k, uint32_t (&w)[NLF], uint32_t (&wfree)[NLF]) __attribute__((always_inline)) {
-            const uint32_t tile = tile_at(k);
-            wait_vmcnt<NLF>(); // everything but the most recent tile's column loads has landed: eps tile k, columns of tile k
-            double e[IPT];
-            lds_eps16(est_addr, lane, e);
-            if (k + 1 < nt) { // issue order: eps tile k + 1, columns of tile k + 2
-                dma_eps(tile_at(k + 1));
-                loads(tile_at(k + 2), wfree);
-            }
-            bool pad_tile;
-            const uint32_t keep = pad_keep(tile, pad_tile);
-            auto weights = [&](uint32_t wd, uint32_t& gwd, uint32_t& nmd) {
-                if constexpr (NOMISS) {
-                    gwd = pad_tile ? (wd & keep) : wd;
-                    nmd = 0x55555555u;
-                } else {
-                    code_weights(wd, gwd, nmd);
-                }
-            };
-            GramPivot gpv[SEG - 1];
-            uint32_t nmp[SEG - 1], xp0 = 0u; // MG: non-missing mask of the pivot, x form of pivot 0
-#pragma unroll
-            for (int q = 0; q < SEG - 1; ++q) {
-                gpv[q] = GramPivot{0u, 0u};
-                nmp[q] = 0u;
-                if (q < ng) {
-                    uint32_t gwq;
-                    weights(w[CPG + q], gwq, nmp[q]);
-                    gpv[q] = gram_pivot(gwq);
-                    if (MG && q == 0) xp0 = gram_xform(gwq);
-                }
-            }
-            if (pend) { // the previous launch's event(s), in order
-#pragma unroll
-                for (int q = 0; q < SEG; ++q)
-                    if (q < npend) apply_update16_asm(w[CPG + SEG - 1 + q], pvt_addr + 256u * (uint32_t)q, e);
-            }
-            uint32_t gw[CPG], nm[CPG];
-#pragma unroll
-            for (int c = 0; c < CPG; ++c) weights(w[c], gw[c], nm[c]);
-            // s1 += (g*nm) * eps: weight 0/1/2 is exact, one rounding per add; each column adds its slots in increasing order
-            if constexpr (CPG % 4 == 0) {
-#pragma unroll
-                for (int c0g = 0; c0g < CPG; c0g += 4)
-                    fma_slots4(gw[c0g], gw[c0g + 1], gw[c0g + 2], gw[c0g + 3], e, a1[c0g], a1[c0g + 1], a1[c0g + 2], a1[c0g + 3],
-                               std::make_integer_sequence<int, IPT>{});
-            } else {
-#pragma unroll
-                for (int s = 0; s < IPT; ++s) {
-#pragma unroll
-                    for (int c = 0; c < CPG; ++c) a1[c] = __builtin_fma((double)((gw[c] >> (2 * s)) & 3u), e[s], a1[c]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CPG; ++c) {
-                if constexpr (!NOMISS) {
-                    if (cmiss[c]) {
-#pragma unroll
-                        for (int s = 0; s < IPT; ++s) a2[c] = __builtin_fma((double)((nm[c] >> (2 * s)) & 1u), e[s], a2[c]);
-                    }
-                }
-                if (cseg[c] > 0) {
-                    const uint32_t xc = gram_xform(gw[c]);
-                    uint32_t g = gram16x(xc, gpv[0]);
-                    if constexpr (MG) {
-                        // B = sum gw_j nm_p, C = sum nm_j gw_p, D = sum nm_j nm_p: popcounts against masks replicated into both bits
-                        const uint32_t nmp2 = nmp[0] | (nmp[0] << 1), nmj2 = nm[c] | (nm[c] << 1);
-                        g |= (uint32_t)__popc(xc & nmp2) << 16;
-                        ag2[c] += (uint32_t)__popc(nmj2 & xp0) | ((uint32_t)__popc(nm[c] & nmp[0]) << 16);
-                    }
-                    if constexpr (SEG > 2) {
-                        if (cseg[c] > 1) g |= gram16x(xc, gpv[1]) << 16;
-                        if (cseg[c] > 2) ag2[c] += gram16x(xc, gpv[SEG > 3 ? 2 : 0]);
-                    }
-                    ag01[c] += g;
-                }
-            }
-        };
-        for (uint32_t k = 0; k < nt; k += 3) {
-            body(k, wA, wC);
-            if (k + 1 < nt) body(k + 1, wB, wA);
-            if (k + 2 < nt) body(k + 2, wC, wB);
-        }
-        wait_vmcnt<0>();
-        __syncthreads(); // every wave is done with its staging tile: the union region may be reused
-        t_loop = dbgp ? wall_clock64() : 0ull;
-        // one cross-lane reduction per launch
-#pragma unroll
-        for (int c = 0; c < CPG; ++c) {
-            const double t1 = wave_sum(a1[c]), t2 = NOMISS ? 0.0 : wave_sum(a2[c]);
-            const uint32_t g0 = any_gram ? wave_sum_u32(ag01[c] & 0xffffu) : 0u;
-            const uint32_t g1 = (MG ? any_gram : ng > 1) ? wave_sum_u32(ag01[c] >> 16) : 0u;
-            const uint32_t g2 = (MG ? any_gram : ng > 2) ? wave_sum_u32(ag2[c] & 0xffffu) : 0u;
-            const uint32_t g3 = (MG && any_gram) ? wave_sum_u32(ag2[c] >> 16) : 0u;
-            if (lane == 0) {
-                double* wp_ = wbase + wave * wstr + NR * c;
-                wp_[0] = t1;
-                wp_[1] = t2;
-                if constexpr (SEG > 1) wp_[2] = (double)g0; // exact: integers far below 2^53
-                if constexpr (MG) {
-                    wp_[3] = (double)g1;
-                    wp_[4] = (double)g2;
-                    wp_[5] = (double)g3;
-                } else {
-                    if constexpr (SEG > 2) wp_[3] = (double)g1;
-                    if constexpr (SEG > 3) wp_[4] = (double)g2;
-                }
-            }
-        }
+        fresh_item(std::false_type{});
     }
     __syncthreads();
 
+    bool drew = false; // this workgroup was the last arriver and ran the draw phase
+    {
     // block partial = waves 0..3 in order, published write-through (sc1); this group's row block starts at group * RB
     const uint32_t rb = group * (uint32_t)RB;
     const uint32_t nrowg = rows_per_col * ncol;
@@ -1273,7 +1322,8 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         sh.flags[F_LAST] = (t == S - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!sh.flags[F_LAST]) return;
+    bool last_of_all = false;
+    if (sh.flags[F_LAST]) { // last workgroup of its group
     if (kind != 0) {
         double* const gred = sh.tot; // rows of a Gram-only group, reduced over the slices, before they are folded per column
         const uint32_t half = tid >> 7, rl = tid & 127u;
@@ -1300,12 +1350,20 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
             // x_j'x_q = mstd_j mstd_q (A_jq - N mave_j mave_q) (no missing calls) or mstd_j mstd_q (A - m_q B - m_j C + m_j m_q D).
             // This rank's part G_j = sum_q dbeta_q mstd_j mstd_q (integer sums over ITS individuals) goes into the column's
             // s1 row: it adds over ranks like every other row; the draw phase adds the carried dot and the N mave mave part.
+            // A column the previous launch streamed AHEAD brings this rank's raw sums instead of a finished dot: they go
+            // into the same row, mstd_j (s1 - mave_j s2) (s2 only where the column has missing calls; the draw phase adds
+            // the common - mstd_j mave_j sum(eps) otherwise).
             __syncthreads();
             if ((uint32_t)tid < ncol) {
                 const uint32_t j = c0 + (uint32_t)tid;
                 const double mj = p.s_mave[d.cursor + j], sj = p.s_mstd[d.cursor + j];
                 const double* r = gred + NRC * tid;
                 double G = 0.0;
+                if (j >= d.carry_left) {
+                    const double* raw = p.ahead_raw + ((size_t)(apar ^ 1u) * AHEAD_MAX + (j - d.carry_left)) * 2;
+                    const bool miss = !NOMISS && (p.s_ga[d.cursor + j] & 0x20000000) != 0;
+                    G = sj * (raw[0] - (miss ? mj * raw[1] : 0.0));
+                }
                 for (int q = 0; q < npend; ++q) {
                     const double db = sh.pev[3 * q], mq = sh.pev[3 * q + 1], sq = sh.pev[3 * q + 2];
                     double a;
@@ -1328,9 +1386,12 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         sh.flags[F_LAST] = (t == nactive - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!sh.flags[F_LAST]) return;
+    last_of_all = sh.flags[F_LAST] != 0;
+    }
 
+    if (last_of_all) {
     // ---- last-arriving workgroup ---------------------------------------------
+    __builtin_amdgcn_s_setprio(3); // the whole chain waits for this workgroup; the others are streaming ahead at priority 0
     if (dbgp && tid == 0) {
         dbgp[1] = wall_clock64();
         dbgp[5] = t_entry;
@@ -1355,6 +1416,8 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     }
     if (tid == 0) {
         __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
+        __hip_atomic_store(p.aqueue + (apar ^ 1u), 0u, HG_RLX_AGENT); // the next launch's ahead queue (nobody is on that half now)
+        __hip_atomic_store(p.aqueue + 2, (uint32_t)(d.seq + 1ull), HG_RLX_AGENT); // go: the totals are here, the others may stream ahead
         sh.flags[F_P2PTMO] = 0u;
     }
     __syncthreads();
@@ -1372,7 +1435,83 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
         for (int r = tid; r < NR * MAX_BATCH; r += BLOCK) p.sums_out[r] = (r < NR * (int)nb) ? sh.tot[r] : 0.0;
         return;
     }
-    sweep_draw_phase<SEG, MG, DBG>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG, NOMISS, DBG>(p, d, nbs, sh);
+    __syncthreads(); // (then on to the ahead queue like everybody else: a launch of a single workgroup has nobody else to serve it)
+    drew = true;
+    }
+
+    // ---- the ahead queue ---------------------------------
+    if (!last_of_all) __builtin_amdgcn_s_setprio(0); // behind the stragglers of the batch and behind the drawing workgroup on this compute unit
+    n_ahead = sweep_ahead_cols<MG, NOMISS>(p, d, nb, sh, tid); // (the staged flags are in place: several barriers ago)
+    a_groups = (n_ahead + CPG - 1) / CPG;
+    {
+        const uint32_t fit = a_groups ? p.resident / a_groups : 1u;
+        a_slices = fit < p.slices_max ? (fit ? fit : 1u) : p.slices_max;
+    }
+    }
+    if (a_groups == 0u) return;
+    if (!drew) {
+        // The hand-off in progress (tickets, partial rows, totals: a chain of memory round trips on the critical path) is
+        // slowed by streaming next to it: the ahead items start when the last arriver has the totals (its go: this
+        // launch's number in the queue's go word).  Bounded wait: without the go the items are simply taken later.
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(p.aqueue + 2, HG_RLX_AGENT) != (uint32_t)(d.seq + 1ull) && wall_clock64() - t0 < 20000ull) // 200 us at 100 MHz
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
+    for (;;) { // items of the ahead queue
+        if (tid == 0) sh.flags[F_POS] = __hip_atomic_fetch_add(p.aqueue + apar, 1u, HG_RLX_AGENT);
+        __syncthreads();
+        const uint32_t aitem = sh.flags[F_POS];
+        __syncthreads();
+        if (aitem >= a_groups * a_slices) return;
+        const uint32_t ag = aitem / a_slices, a0 = ag * CPG;
+        slice = aitem % a_slices;
+        Sw = a_slices;
+        nt = slice < ntg ? (ntg - slice + Sw - 1) / Sw : 0u;
+        c0 = nb + a0;
+        c1 = (c0 + CPG < nb + n_ahead) ? c0 + CPG : nb + n_ahead;
+        ncol = c1 - c0;
+        wbase = sh.wpart;
+        wstr = sh.wstride;
+        fresh_item(std::true_type{});
+        __syncthreads();
+        // publish the item's rows (s1, s2 per column); the last of the item's slices sums them over the slices in order
+        for (uint32_t t = tid; t < 2u * ncol; t += BLOCK) {
+            const uint32_t c = t >> 1, r = t & 1u;
+            double v = wbase[NR * c + r];
+            v += wbase[wstr + NR * c + r];
+            v += wbase[2 * wstr + NR * c + r];
+            v += wbase[3 * wstr + NR * c + r];
+            __hip_atomic_store(p.apartials + (size_t)slice * (2 * AHEAD_MAX) + 2 * (a0 + c) + r, v, HG_RLX_AGENT);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(p.aticket + ag, 1u, HG_RLX_AGENT);
+            sh.flags[F_LAST] = (t == a_slices - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (sh.flags[F_LAST]) {
+            if ((uint32_t)tid < 2u * ncol) { // slices 0..31 then 32..63, all loads of a half in flight, added in order
+                const double* row = p.apartials + 2 * a0 + tid;
+                double acc = 0.0;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    double v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) v[u] = ((uint32_t)(32 * h2 + u) < a_slices) ? __hip_atomic_load(row + (size_t)(32 * h2 + u) * (2 * AHEAD_MAX), HG_RLX_AGENT) : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) acc += v[u];
+                }
+                p.ahead_raw[((size_t)apar * AHEAD_MAX + a0) * 2 + tid] = acc; // read by the next launch
+            }
+            if (tid == 0) __hip_atomic_store(p.aticket + ag, 0u, HG_RLX_AGENT);
+        }
+        __syncthreads();
+    }
 }
 
 // Multi-GPU second half: sums_out has been all-reduced over ranks.
@@ -1399,7 +1538,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_draw(SweepParams p)
     if (threadIdx.x < 3 * MAX_SEG) sh.pev[threadIdx.x] = pend ? p.desc->pend_ev[threadIdx.x / 3][threadIdx.x % 3] : 0.0;
     for (int r = threadIdx.x; r < NR * (int)nb2; r += BLOCK) sh.tot[r] = p.sums_out[r];
     __syncthreads();
-    sweep_draw_phase<SEG, MG, 0>(p, d, nbs, sh);
+    sweep_draw_phase<SEG, MG, 0, 0>(p, d, nbs, sh);
 }
 
 } // namespace hg

@@ -116,7 +116,11 @@ struct hgibbs_ctx {
     double* partials = nullptr;
     double* totals = nullptr;
     double* carry = nullptr; // MAX_BATCH dots handed from one launch to the next
-    bool carry_on = true;    // option carry
+    double* ahead_raw = nullptr; // the ahead phase's buffers (hg_kernels.h: SweepParams)
+    double* apartials = nullptr;
+    uint32_t* aticket = nullptr; // AHEAD_MAX / 2 group tickets, then the two queue counters
+    int ahead = -1;          // option ahead: columns streamed ahead per launch (-1 = auto)
+    int carry_on = -1;       // option carry: -1 auto (on for shards of 400 000 individuals and more), 0 off, 1 on
     uint32_t* ticket = nullptr; // word 0: the launch-wide ticket; words 16.. : one per column group
     double* sums = nullptr;    // 3*MAX_BATCH+1 (multi-GPU exchange buffer)
     double* scratch = nullptr; // reductions
@@ -538,6 +542,10 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
     HIP_TRY(hipMalloc(&h->carry, (size_t)MAX_BATCH * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->ahead_raw, (size_t)2 * AHEAD_MAX * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->apartials, (size_t)S_CAP * 2 * AHEAD_MAX * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->aticket, (AHEAD_MAX / 2 + 4) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->aticket, 0, (AHEAD_MAX / 2 + 4) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->sums, (NROW * MAX_BATCH + 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&h->dbg, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
@@ -557,7 +565,7 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -1083,7 +1091,10 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "gram")) {
         h->gram = value != 0;
     } else if (!std::strcmp(name, "carry")) {
-        h->carry_on = value != 0;
+        h->carry_on = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    } else if (!std::strcmp(name, "ahead")) {
+        if (value < -1 || value > AHEAD_MAX) return fail("ahead must be in [-1,%d] (-1 = auto)", AHEAD_MAX);
+        h->ahead = (int)value;
 
     } else if (!std::strcmp(name, "p2p")) {
         h->p2p_enabled = value != 0;
@@ -1180,6 +1191,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->aticket, 0, (AHEAD_MAX / 2 + 4) * sizeof(uint32_t), h->stream));
     k_gather_meta<<<(M + 255) / 256, 256, 0, h->stream>>>(h->order, h->mave, h->mstd, h->beta, h->groups, h->adaV, h->counts, h->s_mave, h->s_mstd,
                                                        h->s_bold, h->s_ga, M);
     HIP_TRY(hipGetLastError());
@@ -1248,8 +1260,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.gticket = h->ticket + 16;
     p.totals = h->totals;
     p.carry = h->carry;
+    p.ahead_raw = h->ahead_raw;
+    p.apartials = h->apartials;
+    p.aticket = h->aticket;
+    p.aqueue = h->aticket + AHEAD_MAX / 2;
     // the carry term is a 16-bit field per lane like the other Gram partials; a carried column group may run on a single slice
-    p.carry_on = (h->carry_on && h->gram) ? 1u : 0u; // (its Gram terms are 16-bit fields like the pivots': p.gram falls to 0 where they could overflow)
+    // carried dots pay where re-streaming a column costs more than the Gram-only group, its reductions and the extra work of
+    // the group stage and of the draw phase: measured (round 2) -2 % at N = 200 K, -1.5 % at 350 K, +1 % at 500 K, +4 % at
+    // 500 K with missing calls in every column (the fresh dot of such a column costs twice as much), -10 % at 50 K
+    const bool carry_auto = h->n_local >= 400000u;
+    p.carry_on = ((h->carry_on < 0 ? carry_auto : h->carry_on != 0) && h->gram) ? 1u : 0u; // (16-bit Gram fields: p.gram falls to 0 where they could overflow)
+    p.ahead_cols = (uint32_t)(h->ahead >= 0 ? h->ahead : 0); // columns streamed ahead of the batch behind the hand-off (needs carry; off on the split path)
     p.cols_per_group = cpg;
     p.batch_cap = ngroups * cpg;
     p.batch_limit = batch;
@@ -1268,6 +1289,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     if (p.max_seg > (uint32_t)tier) p.max_seg = (uint32_t)tier;
     const int nr = sweep_rows(tier, mg ? 1 : 0);
     const size_t lds = sweep_lds_bytes(p.batch_cap, cpg, K, nr);
+    // 160 KiB of LDS per compute unit, handed out in 1280-byte granules: three workgroups fit only up to 42 granules each
+    if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep LDS %zu B = %zu granules of 1280 B (3 per CU up to 42)\n", lds, (lds + 1279) / 1280);
     const bool use_p2p = h->nranks > 1 && h->p2p_ready && h->p2p_enabled && !h->force_split;
     const bool split = (h->nranks > 1 && !use_p2p) || h->force_split;
     if (h->nranks > 1 && split && !h->comm && !h->ext_fn)
@@ -1289,7 +1312,6 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     const uint32_t groups_max = 1u + (batch + ccg - 1) / ccg + ngroups;
     if (groups_max > (uint32_t)MAX_GROUPS || (uint64_t)groups_max * group_rows((int)cpg, tier, mg ? 1 : 0) > (uint64_t)PROWS_CAP)
         return fail("hgibbs_sweep: %u groups of %d partial rows exceed the partial buffer", groups_max, group_rows((int)cpg, tier, mg ? 1 : 0));
-    const dim3 grid(S * groups_max);
     uint64_t total_launches = 0;
     // the build of the kernel this sweep runs
     void (*kern)(SweepParams) = nullptr;
@@ -1324,6 +1346,11 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         const uint32_t s_min = std::max<uint32_t>(1u, std::min<uint32_t>(S, p.resident / std::max<uint32_t>(1u, groups_max)));
         if ((ntg + s_min - 1) / s_min > 1000u) p.gram = 0;
     }
+    // A launch's active workgroups are the first S * nactive <= resident ones in dispatch order (S is chosen on the device
+    // as resident / groups): the grid never needs more than `resident` workgroups.  Workgroups beyond the active ones leave
+    // at once, but each still has to be given its LDS first -- thousands of them queue for the slots the active ones
+    // hold and keep the kernel alive after its last workgroup has drawn.
+    const dim3 grid(std::min<uint32_t>(S * groups_max, p.resident));
     auto launch_one = [&]() { kern<<<grid, BLOCK, lds, h->stream>>>(p); };
     // launch-bound inner loop: the launches of one sweep are identical (all state travels through the
     // descriptor), so GRAPH_N of them are captured once per sweep into a graph and replayed

@@ -108,14 +108,18 @@ def test_every_build_streams_several_tiles_vs_oracle(oracle, build, slices, carr
     miss_cols, opts = BUILDS[build]
     M, N = 480, 20011
     bed, y = _case(M, N, miss_cols, seed=900 + int(100 * miss_cols))
-    r = _run_vs_oracle(oracle, bed, y, N, dict(opts, batch=256, slices=slices, carry=carry), iters=4,
+    # with carry on, half of the cases also stream ahead of the batch (option ahead: the columns behind the batch are taken
+    # from a queue while the last workgroup draws, and reach the next launch as carried columns with raw sums)
+    ahead = 40 if (carry and slices == 2) else 0
+    r = _run_vs_oracle(oracle, bed, y, N, dict(opts, batch=256, slices=slices, carry=carry, ahead=ahead), iters=4,
                        min_tiles=5 if slices == 1 else 3)
     if carry and build.split(",")[2] == "0":  # the four-term build (MG) carries nothing
         assert r["carried"] > 0, "no column was ever carried: the carry path did not run"
 
 
-@pytest.mark.parametrize("N,miss_cols,max_seg", [(70001, 0.0, 0), (100003, 0.0, 2), (100003, 0.25, 0), (130001, 1.0, 2), (130001, 0.0, 4)])
-def test_large_shard_default_geometry_vs_oracle(oracle, N, miss_cols, max_seg):
+@pytest.mark.parametrize("N,miss_cols,max_seg,carry,ahead", [(70001, 0.0, 0, -1, 0), (100003, 0.0, 2, 1, 64), (100003, 0.25, 0, 1, 0),
+                                                               (130001, 1.0, 2, 1, 128), (130001, 0.0, 4, -1, 0), (70001, 0.1, 2, 1, 256)])
+def test_large_shard_default_geometry_vs_oracle(oracle, N, miss_cols, max_seg, carry, ahead):
     """Shapes of 70 K-130 K individuals with the library's own launch geometry (64 column groups of four columns,
     slices = co-resident workgroups / groups): 18-32 tile groups over 12 slices, two to three per workgroup, three
     iterations, with and without missing calls (the NOMISS, plain and four-term builds) -- what configs 3 and 4 run,
@@ -123,6 +127,7 @@ def test_large_shard_default_geometry_vs_oracle(oracle, N, miss_cols, max_seg):
     M = 400
     bed, y = _case(M, N, miss_cols, seed=77 + N % 100, causal=0.05)
     opts = {"max_seg": max_seg} if max_seg else {}
+    opts.update({"carry": carry, "ahead": ahead})  # carried dots are off by default below 400 000 individuals: forced on in some cases
     _run_vs_oracle(oracle, bed, y, N, opts, iters=3)
 
 
@@ -237,12 +242,12 @@ def _two_ranks_vs_oracle(oracle, exchange, M, N, iters, opts, miss=0.0, min_tile
 def test_two_ranks_mailbox_large_shards_vs_oracle(oracle):
     """In-launch peer mailboxes, 55 002 individuals per rank (14 tile groups over 12 slices: two for some workgroups),
     default options (four-segment build, carried dots: the carry term is one of the exchanged rows)."""
-    _two_ranks_vs_oracle(oracle, "p2p", M=500, N=110004, iters=3, opts={})
+    _two_ranks_vs_oracle(oracle, "p2p", M=500, N=110004, iters=3, opts={"carry": 1, "ahead": 48})
 
 
 def test_two_ranks_mailbox_few_slices_vs_oracle(oracle):
     """The same exchange with two slices only: seven tile groups per workgroup on every rank, missing calls."""
-    _two_ranks_vs_oracle(oracle, "p2p", M=400, N=110004, iters=3, opts={"slices": 2, "max_seg": 2}, miss=0.01, min_tiles=7)
+    _two_ranks_vs_oracle(oracle, "p2p", M=400, N=110004, iters=3, opts={"slices": 2, "max_seg": 2, "carry": 1}, miss=0.01, min_tiles=7)
 
 
 def test_two_ranks_split_path_large_shards_vs_oracle(oracle):
