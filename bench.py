@@ -444,6 +444,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
+    # one more (untimed) iteration on the build with stage timestamps: every rank runs it (the chain is collective)
+    anatomy_all = None
+    if not args.no_anatomy:
+        try:
+            anatomy_all = launch_anatomy(dev, chain)
+        except Exception as e:
+            print("launch anatomy not measured: %r" % (e,), file=sys.stderr)
+
     if rank == 0:
         K = args.steps
         ms_per_step = dt / K * 1e3
@@ -463,12 +471,7 @@ def main():
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
         traffic, traffic_src = committed_profile("traffic", N, M, world)
         valu, valu_src = committed_profile("valu", N, M, world)
-        anatomy = None
-        if not args.no_anatomy and world == 1:
-            try:
-                anatomy = launch_anatomy(dev, chain)
-            except Exception as e:
-                print("launch anatomy not measured: %r" % (e,), file=sys.stderr)
+        anatomy = anatomy_all  # measured by every rank together (below the timed region), reported by rank 0
         col_bytes = (n_local + 3) // 4
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic["traffic_bytes_per_launch"] if traffic else None, "traffic_source": traffic_src,

@@ -17,7 +17,11 @@
 //                 column that is an event (slab chosen, or an effect that was non-zero) straight
 //                 into pinned host memory.
 //   k_bw_refresh  eps += delta(genotype) for the event's marker fused with vi = exp(alpha*eps - EuMasc)
-//                 and the block partials of sum(vi).
+//                 and the block partials of sum(vi).  Inside a sweep this pass rides in the NEXT batch's k_bw_sums
+//                 (the pending update, as in the BayesR sweep): one extra group of workgroups stores the other eps / vi
+//                 buffers and the block partials, the streaming groups take vi * exp(alpha*delta(genotype)) -- three
+//                 constants, from a pair table in LDS -- on their tile in registers.  The kernel itself remains for the
+//                 single-marker operators and for the last event of a sweep.
 //   k_bw_reduce   the N-length sums inside the log densities of mu, alpha and the covariates.
 // The uniforms are one u32 per marker in sweep order, so they are generated up front; the ARS
 // draw runs on the host between launches (hg_ars.h), on scalars the launch hands back.
@@ -48,6 +52,13 @@ struct BwBatchParams {
     uint32_t ncols;         // columns whose effect is zero
     int32_t shifted_marker; // -1, or the marker right after them whose effect is not zero
     double dv[3];           // what eps gains per genotype when that effect is taken out
+    // the previous batch's event, not applied yet (pend_marker >= 0): eps gains pend_dv[genotype], vi is multiplied by
+    // pend_f[genotype] = exp(alpha * pend_dv[genotype]); the update group stores eps_out / vi_out (vi recomputed with exp)
+    int32_t pend_marker;
+    double pend_dv[3], pend_f[3];
+    double* eps_out;
+    double* vi_out;
+    double* vipart_out;     // block partials of sum(vi_out) (read by this batch's tail)
     double alpha;
     uint32_t slices;
     double* partials; // [slice][BW_ROWS]
@@ -234,11 +245,22 @@ template <int CPG>
 __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
 {
     __shared__ double wpart[BLOCK_WAVES][2 * CPG + 4];
+    __shared__ double2 ftab[16], atab[16]; // the pending update over a PAIR of codes: factors of vi, addends of eps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ngn = (p.ncols + CPG - 1) / CPG;
     const uint32_t S = p.slices;
     const uint32_t slice = blockIdx.x % S, group = blockIdx.x / S;
     const uint32_t ntg = p.n_pad / BLOCK_IND;
+    const bool pend = p.pend_marker >= 0;
+    if (pend && tid < 16) {
+        auto fac = [&](uint32_t c) { return (c == GC_G0) ? p.pend_f[0] : ((c == GC_G1) ? p.pend_f[1] : ((c == GC_G2) ? p.pend_f[2] : 1.0)); };
+        auto add = [&](uint32_t c) { return 0.0 + ((c == GC_G0) ? p.pend_dv[0] : ((c == GC_G1) ? p.pend_dv[1] : ((c == GC_G2) ? p.pend_dv[2] : 0.0))); };
+        ftab[tid] = make_double2(fac((uint32_t)tid & 3u), fac(((uint32_t)tid >> 2) & 3u));
+        atab[tid] = make_double2(add((uint32_t)tid & 3u), add(((uint32_t)tid >> 2) & 3u));
+    }
+    const uint8_t* pendp = p.bed + (size_t)(pend ? p.pend_marker : 0) * p.stride + (lane << 2);
+    __syncthreads();
+    const uint32_t nshift = p.shifted_marker >= 0 ? 1u : 0u;
 
     if (group < ngn) {
         const uint32_t c0 = group * CPG;
@@ -255,6 +277,15 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             double e[IPT];
             load_eps16(p.vi, tile, lane, e);
+            if (pend) { // vi with the pending update: exp(alpha (eps + delta) - EuMasc) = vi * exp(alpha delta), delta one of three constants
+                const uint32_t wq = *reinterpret_cast<const uint32_t*>(pendp + ((size_t)tile << 8));
+#pragma unroll
+                for (int s2 = 0; s2 < IPT; s2 += 2) {
+                    const double2 f = ftab[(wq >> (2 * s2)) & 15u];
+                    e[s2] = e[s2] * f.x;
+                    e[s2 + 1] = e[s2 + 1] * f.y;
+                }
+            }
             uint32_t m1[CPG], m2[CPG];
 #pragma unroll
             for (int c = 0; c < CPG; ++c) {
@@ -284,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
             v += wpart[3][tid];
             __hip_atomic_store(p.partials + (size_t)slice * BW_ROWS + 2 * c0 + tid, v, HG_RLX_AGENT);
         }
-    } else {
+    } else if (group < ngn + nshift) {
         // the marker whose effect is not zero: vi as it would be with that effect taken out (src/BayesW.cpp:1499-1516)
         const uint8_t* colp = p.bed + (size_t)p.shifted_marker * p.stride + (lane << 2);
         double s = 0.0, s1 = 0.0, s2 = 0.0;
@@ -292,6 +323,7 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             double e[IPT];
             load_eps16(p.eps, tile, lane, e);
+            if (pend) apply_update16_lds(*reinterpret_cast<const uint32_t*>(pendp + ((size_t)tile << 8)), atab, e);
             const uint32_t w = *reinterpret_cast<const uint32_t*>(colp + ((size_t)tile << 8));
             const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
 #pragma unroll
@@ -319,6 +351,33 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
             v += wpart[2][tid];
             v += wpart[3][tid];
             __hip_atomic_store(p.partials + (size_t)slice * BW_ROWS + 2 * MAX_BATCH + tid, v, HG_RLX_AGENT);
+        }
+    } else if (pend) {
+        // the update group: the pending event's pass over eps and vi (what k_bw_refresh does on its own launch): the other eps
+        // and vi buffers and the block partials of sum(vi), src/BayesW.cpp:1606-1622, :1812, :1832-1834
+        for (uint32_t tg = slice; tg < ntg; tg += S) {
+            const uint32_t tile = tg * BLOCK_WAVES + wave;
+            double e[IPT], v[IPT];
+            load_eps16(p.eps, tile, lane, e);
+            apply_update16_lds(*reinterpret_cast<const uint32_t*>(pendp + ((size_t)tile << 8)), atab, e);
+            store_eps16(p.eps_out, tile, lane, e);
+            const uint32_t i0 = (tile << 10) + ((uint32_t)lane << 4);
+            double sv = 0.0;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                v[k] = (i0 + k < p.n_local) ? exp(p.alpha * e[k] - bw::EULER) : 0.0;
+                sv += v[k];
+            }
+            store_eps16(p.vi_out, tile, lane, v);
+            sv = wave_sum(sv);
+            __syncthreads(); // the previous tile group's partial has been read
+            if (lane == 0) wpart[wave][0] = sv;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int w2 = 0; w2 < BLOCK_WAVES; ++w2) t += wpart[w2][0];
+                p.vipart_out[tg] = t;
+            }
         }
     }
 }
@@ -458,6 +517,7 @@ __global__ __launch_bounds__(WAVE) void k_bw_tail(BwBatchParams p)
 // ---------------------------------------------------------------------------
 struct BwState {
     double* vi = nullptr;
+    double* vi2 = nullptr; // the other vi buffer: a batch that applies a pending update writes it (k_bw_sums' update group)
     uint32_t* failspread = nullptr;
     double* vi_sum = nullptr; // device scalar
     double *d_mave = nullptr, *d_sd = nullptr, *d_sumfail = nullptr;
@@ -486,7 +546,7 @@ struct BwState {
 static void bw_free(BwState* b)
 {
     if (!b) return;
-    void* ptrs[] = {b->vi, b->failspread, b->vi_sum, b->d_mave, b->d_sd, b->d_sumfail, b->d_cva, b->d_pi, b->d_sigmaG, b->d_ghx, b->d_ghw,
+    void* ptrs[] = {b->vi, b->vi2, b->failspread, b->vi_sum, b->d_mave, b->d_sd, b->d_sumfail, b->d_cva, b->d_pi, b->d_sigmaG, b->d_ghx, b->d_ghw,
                     b->d_unif, b->partials, b->d_picks, b->d_colsums, b->vipart, b->d_colk, b->d_first_event, b->d_rows};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -530,6 +590,8 @@ int hgibbs_w_init(hgibbs_t h, const int32_t* failure_host)
     const uint32_t ndw = h->n_pad / 16;
     HIP_TRY(hipMalloc(&b->vi, (size_t)h->n_pad * sizeof(double)));
     HIP_TRY(hipMemsetAsync(b->vi, 0, (size_t)h->n_pad * sizeof(double), h->stream));
+    HIP_TRY(hipMalloc(&b->vi2, (size_t)h->n_pad * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(b->vi2, 0, (size_t)h->n_pad * sizeof(double), h->stream));
     HIP_TRY(hipMalloc(&b->failspread, (size_t)ndw * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&b->vi_sum, sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_mave, (size_t)h->M * sizeof(double)));
@@ -785,6 +847,9 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     uint32_t cursor = 0;
     hg::GlibcRand* gr = reinterpret_cast<hg::GlibcRand*>(ars_rng);
+    // the last event's update of eps and vi, applied by the next batch's launch (or flushed behind the loop)
+    int32_t pend_marker = -1;
+    double pend_dv[3] = {0.0, 0.0, 0.0};
     while (cursor < M) {
         // columns with a zero effect, then (if it comes within reach) the first marker whose effect is not zero
         uint32_t ncols = 0;
@@ -816,7 +881,15 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
             p.dv[2] = dv[2];
         }
         p.alpha = alpha;
-        const uint32_t ngroups = (ncols + CPG - 1) / CPG + (shifted >= 0 ? 1u : 0u);
+        p.pend_marker = pend_marker;
+        for (int c = 0; c < 3; ++c) {
+            p.pend_dv[c] = pend_dv[c];
+            p.pend_f[c] = std::exp(alpha * pend_dv[c]);
+        }
+        p.eps_out = h->eps[h->eps_cur ^ 1u];
+        p.vi_out = b->vi2;
+        p.vipart_out = b->vipart;
+        const uint32_t ngroups = (ncols + CPG - 1) / CPG + (shifted >= 0 ? 1u : 0u) + (pend_marker >= 0 ? 1u : 0u);
         uint32_t S = h->slices ? h->slices : S_CAP;
         S = std::min<uint32_t>(std::min<uint32_t>(S, S_CAP), ntg);
         S = std::max<uint32_t>(1u, std::min<uint32_t>(S, 768u / ngroups));
@@ -847,6 +920,11 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk0, h->stream));
         k_bw_sums<CPG><<<S * ngroups, BLOCK, 0, h->stream>>>(p);
         if (h->w_kernel_timing) HIP_TRY(hipEventRecord(b->evk1, h->stream));
+        if (pend_marker >= 0) { // the launch wrote the other eps / vi buffers: they are the current ones from here on
+            h->eps_cur ^= 1u;
+            std::swap(b->vi, b->vi2);
+            pend_marker = -1;
+        }
         if (p.rows) { // individuals sharded: the row sums add over the ranks, same bits everywhere
             k_bw_rows<<<nb + 1, WAVE, 0, h->stream>>>(p);
             HIP_TRY(hipGetLastError());
@@ -918,13 +996,16 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         b->beta[mk] = beta_new;
         const double deltaBeta = beta_old - beta_new;
         if (deltaBeta != 0.0) { // src/BayesW.cpp:1606-1622, :1812, :1832-1834
-            double dv[3];
-            bw::delta_values(deltaBeta, b->mave[mk], b->sd[mk], dv);
-            k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, mk, dv[0], dv[1], dv[2], h->eps[h->eps_cur], b->vi, alpha, h->n_local,
-                                                        b->vipart);
+            bw::delta_values(deltaBeta, b->mave[mk], b->sd[mk], pend_dv);
+            pend_marker = mk; // rides in the next batch's launch
             ++nnz;
         }
         cursor += r.event + 1;
+    }
+    if (pend_marker >= 0) { // the sweep's last event: its pass on its own
+        k_bw_refresh<<<nblk, BLOCK, 0, h->stream>>>(h->bed, h->stride, pend_marker, pend_dv[0], pend_dv[1], pend_dv[2], h->eps[h->eps_cur], b->vi, alpha,
+                                                    h->n_local, b->vipart);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
