@@ -65,12 +65,13 @@ constexpr int NROW = NSUM + 4;           // most rows per batch column in `total
 // Gram term, or A, B, C, D
 __host__ __device__ constexpr int sweep_rows(int seg, int mg) { return NSUM + (seg - 1) * (mg ? 4 : 1); }
 // carried columns per Gram-only workgroup, and the rows such a group publishes per column (per pending update and per earlier pivot)
-__host__ __device__ constexpr int carried_cpg(int mg) { return mg ? 8 : 16; }
+// (8 where a column takes many terms -- four sums per term, or the four-segment build's seven terms: registers)
+__host__ __device__ constexpr int carried_cpg(int seg, int mg) { return (mg || seg > 2) ? 8 : 16; }
 __host__ __device__ constexpr int carried_rows(int seg, int mg) { return (seg + seg - 1) * (mg ? 4 : 1); }
 // row block of one group (slices x this many rows) in `partials`
 __host__ __device__ constexpr int group_rows(int cpg, int seg, int mg)
 {
-    return carried_cpg(mg) * carried_rows(seg, mg) > cpg * sweep_rows(seg, mg) ? carried_cpg(mg) * carried_rows(seg, mg) : cpg * sweep_rows(seg, mg);
+    return carried_cpg(seg, mg) * carried_rows(seg, mg) > cpg * sweep_rows(seg, mg) ? carried_cpg(seg, mg) * carried_rows(seg, mg) : cpg * sweep_rows(seg, mg);
 }
 constexpr int MAX_GROUPS = 1 + MAX_BATCH / 8 + MAX_BATCH / 2; // update group + Gram-only groups + fresh groups at their smallest sizes
 constexpr int PROWS_CAP = 10240;         // partial rows per slice: groups x group_rows of any build (checked on the host)
@@ -89,9 +90,6 @@ struct SweepDesc {
                                   // Gram correction for every earlier pivot
     uint32_t rng_idx;       // MT19937 position (0..624)
     uint32_t error;         // non-zero: 1 logL overflow abort (src/BayesRRm.cpp:1910-1913), 2 rng staging overrun, 3 peer timeout
-    uint64_t nnz;           // markers with deltaBeta != 0 so far
-    uint64_t launches;      // launches that did work
-    uint64_t accepted_sum;  // total accepted markers (== cursor at the end)
     uint64_t seq;           // batches since the handle was created (epoch of the cross-GPU exchange)
     // carried dots: the first carry_n columns of the next batch were already streamed by this launch (they lay behind the
     // event that ended it); their dots against THIS launch's residual are in SweepParams::carry, and the next launch only
@@ -100,8 +98,16 @@ struct SweepDesc {
     uint32_t carry_left;    // the first carry_left of them were left over by this launch's walk (dots in SweepParams::carry); the rest it
                             // streamed ahead (raw sums in SweepParams::ahead_raw)
     double pend_ev[MAX_SEG][3]; // (dbeta, mave, mstd) of the pending updates: what the Gram correction of a carried dot needs
-    uint64_t carried_sum;   // columns carried so far (statistics)
-    uint64_t streamed_sum;  // batch columns whose dot was streamed (planned columns minus the carried ones), statistics
+};
+
+// Counters of a sweep, behind the descriptor in memory: the draw phase only ADDS to them (atomics without return), so that the
+// descriptor it hands to the next launch is written from registers without a load in front of it.
+struct SweepCounters {
+    unsigned long long nnz;           // markers with deltaBeta != 0 so far
+    unsigned long long launches;      // launches that did work
+    unsigned long long accepted_sum;  // total accepted markers (== cursor at the end)
+    unsigned long long carried_sum;   // columns carried so far
+    unsigned long long streamed_sum;  // batch columns whose dot was streamed (carried ones not, ahead ones included)
     uint32_t tiles_min;     // fewest / most tile groups (4096 individuals) one workgroup streamed in a working launch of this sweep:
     uint32_t tiles_max;     // > 1 means the loop's next-tile prefetch and the accumulation across tiles ran
 };
@@ -153,6 +159,7 @@ struct SweepParams {
     ZigTables zig;
     // hand-off
     SweepDesc* desc;
+    SweepCounters* counters;
     double* carry;         // [MAX_BATCH] dots of the carried columns (written by the draw phase, read by the next one)
     uint32_t carry_on;     // 1: launches may hand dots of already streamed columns to the next one
     uint32_t ahead_cols;   // columns a launch streams ahead of its batch while its last workgroup draws (0: none)

@@ -261,9 +261,9 @@ __device__ __forceinline__ uint32_t sweep_ahead_cols(const SweepParams& p, const
 }
 
 // groups of a launch: the update group (when updates are pending), Gram-only groups of the carried columns, fresh groups
-__device__ __forceinline__ uint32_t sweep_groups(const SweepParams& p, const DescHead& d, uint32_t nb, int mg)
+__device__ __forceinline__ uint32_t sweep_groups(const SweepParams& p, const DescHead& d, uint32_t nb, int seg, int mg)
 {
-    const uint32_t ncar = sweep_carried(p, d, nb), ccg = (uint32_t)carried_cpg(mg);
+    const uint32_t ncar = sweep_carried(p, d, nb), ccg = (uint32_t)carried_cpg(seg, mg);
     return (d.pend_marker[0] >= 0 ? 1u : 0u) + (ncar + ccg - 1) / ccg + (nb - ncar + p.cols_per_group - 1) / p.cols_per_group;
 }
 
@@ -632,9 +632,9 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         }
     }
     if (tid == 0) {
-        SweepDesc n = *p.desc; // counters come from memory; only this thread needs them
+        SweepDesc n; // every field from registers / LDS: no load in front of the hand-over (the counters live behind it, see SweepCounters)
         n.cursor = d.cursor + naccept;
-        if (d.pend_marker[0] >= 0) n.cur = d.cur ^ 1u;
+        n.cur = (d.pend_marker[0] >= 0) ? d.cur ^ 1u : d.cur;
         for (int q = 0; q < MAX_SEG; ++q) {
             n.pend_marker[q] = sh.pmk[q];
             for (int c = 0; c < 3; ++c) {
@@ -642,26 +642,28 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
                 n.pend_ev[q][c] = sh.pel[3 * q + c];
             }
         }
-        n.nnz += nnz_add;
         n.rng_idx = (pos >= (uint32_t)MT_N) ? pos - (uint32_t)MT_N : pos;
-        n.launches += 1;
         n.seq = d.seq + 1;
-        n.accepted_sum += naccept;
-        if (sh.flags[F_ERR]) n.error = sh.flags[F_ERR];
+        n.error = sh.flags[F_ERR] ? sh.flags[F_ERR] : d.error;
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         n.carry_n = carry_next;
         n.carry_left = carry_left;
-        {
-            const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, sweep_groups(p, d, nb, MG));
-            const uint32_t tiles = (ntg + S - 1) / S;
-            n.streamed_sum += nb - ncarry + n_ahead;
-            if (nb > ncarry) {
-                n.tiles_min = tiles < n.tiles_min ? tiles : n.tiles_min;
-                n.tiles_max = tiles > n.tiles_max ? tiles : n.tiles_max;
-            }
-        }
-        n.carried_sum += carry_next;
         *p.desc = n;
+        { // the sweep's counters: a read-modify-write of their own, off the hand-over's path
+            SweepCounters c = *p.counters;
+            c.nnz += nnz_add;
+            c.launches += 1;
+            c.accepted_sum += naccept;
+            c.carried_sum += carry_next;
+            c.streamed_sum += nb - ncarry + n_ahead;
+            if (nb > ncarry) {
+                const uint32_t ntg = p.n_pad / BLOCK_IND, S = sweep_slices(p, sweep_groups(p, d, nb, SEG, MG));
+                const uint32_t tiles = (ntg + S - 1) / S;
+                c.tiles_min = tiles < c.tiles_min ? tiles : c.tiles_min;
+                c.tiles_max = tiles > c.tiles_max ? tiles : c.tiles_max;
+            }
+            *p.counters = c;
+        }
         if (dbgp) { // accumulate stage durations over all launches: [8+i] += t[i+1]-t[i], [15] = count
             dbgp[4] = wall_clock64();
             for (int i = 0; i < 4; ++i) dbgp[8 + i] += dbgp[i + 1] - dbgp[i];
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_swe
     static_assert(!MG || SEG == 2, "the missing-call Gram terms are carried by the two-segment build only");
     constexpr int NR = sweep_rows(SEG, MG);     // rows per batch column in `totals`: s1 (or G_j), s2, T per earlier pivot
     constexpr int T = MG ? 4 : 1;               // integer sums per Gram term
-    constexpr int CCG = carried_cpg(MG);        // carried columns per Gram-only workgroup
+    constexpr int CCG = carried_cpg(SEG, MG);   // carried columns per Gram-only workgroup
     constexpr int NRC = carried_rows(SEG, MG);  // rows a Gram-only group publishes per column: T per pending update, T per pivot
     constexpr int RB = group_rows(CPG, SEG, MG); // row block of one group in `partials`
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);

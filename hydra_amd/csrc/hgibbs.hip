@@ -536,8 +536,8 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemcpy(h->zig + 129, HG_ZIG_NORMAL_Y, 129 * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->zig + 258, HG_ZIG_EXP_X, 257 * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->zig + 515, HG_ZIG_EXP_Y, 257 * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc)));
-    HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc)));
+    HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc) + sizeof(SweepCounters)));      // descriptor, then the sweep's counters
+    HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc) + sizeof(SweepCounters)));
     HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_GROUPS) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
@@ -1208,9 +1208,11 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     d0.cur = h->eps_cur;
     d0.rng_idx = rng->idx;
     d0.seq = h->batch_seq;
-    d0.tiles_min = 0xffffffffu;
     *h->desc_host = d0;
-    HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc), hipMemcpyHostToDevice, h->stream));
+    SweepCounters* const cnt_host = reinterpret_cast<SweepCounters*>(h->desc_host + 1);
+    *cnt_host = SweepCounters{};
+    cnt_host->tiles_min = 0xffffffffu;
+    HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc) + sizeof(SweepCounters), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream)); // staging buffers are on the host stack / pageable
 
     SweepParams p{};
@@ -1255,6 +1257,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.mt = h->mt;
     p.zig = ZigTables{h->zig, h->zig + 129, h->zig + 258, h->zig + 515};
     p.desc = h->desc;
+    p.counters = reinterpret_cast<SweepCounters*>(h->desc + 1);
     p.partials = h->partials;
     p.ticket = h->ticket;
     p.gticket = h->ticket + 16;
@@ -1308,7 +1311,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.slices_max = S;
     // most groups a launch can have: the update group, Gram-only groups of carried columns, fresh groups (a batch is at most
     // `batch` columns, split between the last two kinds)
-    const uint32_t ccg = (uint32_t)carried_cpg(mg ? 1 : 0);
+    const uint32_t ccg = (uint32_t)carried_cpg(tier, mg ? 1 : 0);
     const uint32_t groups_max = 1u + (batch + ccg - 1) / ccg + ngroups;
     if (groups_max > (uint32_t)MAX_GROUPS || (uint64_t)groups_max * group_rows((int)cpg, tier, mg ? 1 : 0) > (uint64_t)PROWS_CAP)
         return fail("hgibbs_sweep: %u groups of %d partial rows exceed the partial buffer", groups_max, group_rows((int)cpg, tier, mg ? 1 : 0));
@@ -1387,10 +1390,10 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         }
         total_launches += (uint64_t)n;
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->desc_host, h->desc, sizeof(SweepDesc), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->desc_host, h->desc, sizeof(SweepDesc) + sizeof(SweepCounters), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out)", dh.error, dh.cursor);
-        if (dh.launches > 0) avg_accept = std::max(1.0, (double)dh.accepted_sum / (double)dh.launches);
+        if (cnt_host->launches > 0) avg_accept = std::max(1.0, (double)cnt_host->accepted_sum / (double)cnt_host->launches);
         if (dh.cursor >= M && dh.pend_marker[0] < 0) break;
         // every launch accepts at least one marker or flushes a pending update: a sweep that needs more
         // than 2M launches (plus one chunk of overshoot) is stuck, not slow
@@ -1409,20 +1412,20 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     rng->idx = h->desc_host->rng_idx;
     HIP_TRY(hipMemcpy(rng->x, h->mt, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (cass_host) HIP_TRY(hipMemcpy(cass_host, h->cass, (size_t)G * K * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (nnz_updates) *nnz_updates = h->desc_host->nnz;
+    if (nnz_updates) *nnz_updates = cnt_host->nnz;
     h->stats.launches = total_launches;
-    h->stats.nnz_updates = h->desc_host->nnz;
-    h->stats.carried_columns = h->desc_host->carried_sum;
-    if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep: %llu launches, %llu columns carried\n", (unsigned long long)total_launches, (unsigned long long)h->desc_host->carried_sum);
+    h->stats.nnz_updates = cnt_host->nnz;
+    h->stats.carried_columns = cnt_host->carried_sum;
+    if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] sweep: %llu launches, %llu columns carried\n", (unsigned long long)total_launches, (unsigned long long)cnt_host->carried_sum);
     h->stats.device_ms = ms;
     // launches that did work (the chunks the host enqueues overshoot the end of the sweep by a few launches that find
     // nothing left and return at once): the average below is taken over the working ones
-    h->stats.working_launches = h->desc_host->launches;
-    h->stats.accepted_markers = h->desc_host->accepted_sum;
-    h->stats.streamed_columns = h->desc_host->streamed_sum;
-    h->stats.tiles_per_workgroup_min = h->desc_host->tiles_max ? h->desc_host->tiles_min : 0u;
-    h->stats.tiles_per_workgroup_max = h->desc_host->tiles_max;
-    h->stats.kernel_ms_avg = h->desc_host->launches ? ms / (double)h->desc_host->launches : 0.0;
+    h->stats.working_launches = cnt_host->launches;
+    h->stats.accepted_markers = cnt_host->accepted_sum;
+    h->stats.streamed_columns = cnt_host->streamed_sum;
+    h->stats.tiles_per_workgroup_min = cnt_host->tiles_max ? cnt_host->tiles_min : 0u;
+    h->stats.tiles_per_workgroup_max = cnt_host->tiles_max;
+    h->stats.kernel_ms_avg = cnt_host->launches ? ms / (double)cnt_host->launches : 0.0;
     return 0;
 }
 
