@@ -851,7 +851,7 @@ __device__ __forceinline__ void wait_vmcnt()
 // reductions are compiled out (s2 is the sum of eps for every column).
 // DBG: stage timestamps (option debug_timing); the production builds carry none of it.
 template <int CPG, int SEG, int MG, int NOMISS = 0, int DBG = 0>
-__global__ __launch_bounds__(BLOCK, ((CPG <= 8 && SEG <= 2) ? 3 : 2)) void k_sweep_batch(SweepParams p)
+__global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 2)) void k_sweep_batch(SweepParams p)
 {
     unsigned long long* const dbgp = DBG ? p.dbg : nullptr;
     static_assert(!(MG && NOMISS), "the missing-call Gram build is for data with missing calls");
