@@ -166,7 +166,7 @@ struct SweepParams {
     double* ahead_raw;     // [2][AHEAD_MAX][2]: (s1, s2) of the columns streamed ahead, by launch parity
     double* apartials;     // [S_CAP][2 * AHEAD_MAX]: their per-slice rows
     uint32_t* aticket;     // [AHEAD_MAX / 2]: per ahead group, slices that have stored their rows
-    uint32_t* aqueue;      // [2]: next item of the ahead queue, by launch parity; [2]: go word (the number of the launch whose hand-off is over)
+    uint32_t* aqueue;      // [2]: next item of the ahead queue, by launch parity
     double* partials;      // [S_CAP][PROWS_CAP]: per slice, one row block per group, written sc1
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals

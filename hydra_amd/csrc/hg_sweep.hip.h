@@ -1419,7 +1419,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     if (tid == 0) {
         __hip_atomic_store(p.ticket, 0u, HG_RLX_AGENT);
         __hip_atomic_store(p.aqueue + (apar ^ 1u), 0u, HG_RLX_AGENT); // the next launch's ahead queue (nobody is on that half now)
-        __hip_atomic_store(p.aqueue + 2, (uint32_t)(d.seq + 1ull), HG_RLX_AGENT); // go: the totals are here, the others may stream ahead
         sh.flags[F_P2PTMO] = 0u;
     }
     __syncthreads();
@@ -1452,17 +1451,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     }
     }
     if (a_groups == 0u) return;
-    if (!drew) {
-        // The hand-off in progress (tickets, partial rows, totals: a chain of memory round trips on the critical path) is
-        // slowed by streaming next to it: the ahead items start when the last arriver has the totals (its go: this
-        // launch's number in the queue's go word).  Bounded wait: without the go the items are simply taken later.
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(p.aqueue + 2, HG_RLX_AGENT) != (uint32_t)(d.seq + 1ull) && wall_clock64() - t0 < 20000ull) // 200 us at 100 MHz
-                __builtin_amdgcn_s_sleep(16);
-        }
-        __syncthreads();
-    }
     for (;;) { // items of the ahead queue
         if (tid == 0) sh.flags[F_POS] = __hip_atomic_fetch_add(p.aqueue + apar, 1u, HG_RLX_AGENT);
         __syncthreads();
