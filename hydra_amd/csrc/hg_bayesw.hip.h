@@ -59,6 +59,7 @@ struct BwBatchParams {
     double* eps_out;
     double* vi_out;
     double* vipart_out;     // block partials of sum(vi_out) (read by this batch's tail)
+    uint32_t upd_groups;    // groups of workgroups that share the update pass (its tiles cost several times a streaming tile: exp per individual)
     double alpha;
     uint32_t slices;
     double* partials; // [slice][BW_ROWS]
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(BLOCK, 3) void k_bw_sums(BwBatchParams p)
     } else if (pend) {
         // the update group: the pending event's pass over eps and vi (what k_bw_refresh does on its own launch): the other eps
         // and vi buffers and the block partials of sum(vi), src/BayesW.cpp:1606-1622, :1812, :1832-1834
-        for (uint32_t tg = slice; tg < ntg; tg += S) {
+        const uint32_t su = (group - (ngn + nshift)) * S + slice, SU = S * p.upd_groups; // this workgroup's place among the update workgroups
+        for (uint32_t tg = su; tg < ntg; tg += SU) {
             const uint32_t tile = tg * BLOCK_WAVES + wave;
             double e[IPT], v[IPT];
             load_eps16(p.eps, tile, lane, e);
@@ -889,7 +891,9 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
         p.eps_out = h->eps[h->eps_cur ^ 1u];
         p.vi_out = b->vi2;
         p.vipart_out = b->vipart;
-        const uint32_t ngroups = (ncols + CPG - 1) / CPG + (shifted >= 0 ? 1u : 0u) + (pend_marker >= 0 ? 1u : 0u);
+        // the update pass costs about four streaming tiles per tile (sixteen exponentials per lane): it gets four groups of workgroups
+        p.upd_groups = 4u;
+        const uint32_t ngroups = (ncols + CPG - 1) / CPG + (shifted >= 0 ? 1u : 0u) + (pend_marker >= 0 ? p.upd_groups : 0u);
         uint32_t S = h->slices ? h->slices : S_CAP;
         S = std::min<uint32_t>(std::min<uint32_t>(S, S_CAP), ntg);
         S = std::max<uint32_t>(1u, std::min<uint32_t>(S, 768u / ngroups));
