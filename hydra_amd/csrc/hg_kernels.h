@@ -89,7 +89,7 @@ struct SweepDesc {
                                   // followed by another one ends ON a predicted event (its pivot); later segments' dots get the
                                   // Gram correction for every earlier pivot
     uint32_t rng_idx;       // MT19937 position (0..624)
-    uint32_t error;         // non-zero: 1 logL overflow abort (src/BayesRRm.cpp:1910-1913), 2 rng staging overrun, 3 peer timeout
+    uint32_t error;         // non-zero: 1 logL overflow abort (src/BayesRRm.cpp:1910-1913), 2 rng staging overrun, 3 peer timeout, 4 LDS base not on a 256-byte boundary
     uint64_t seq;           // batches since the handle was created (epoch of the cross-GPU exchange)
     // carried dots: the first carry_n columns of the next batch were already streamed by this launch (they lay behind the
     // event that ended it); their dots against THIS launch's residual are in SweepParams::carry, and the next launch only
@@ -331,12 +331,17 @@ __device__ __forceinline__ void lds_eps16(uint32_t tile_addr, int lane, double (
     e[8] = v4.x; e[9] = v4.y; e[10] = v5.x; e[11] = v5.y; e[12] = v6.x; e[13] = v6.y; e[14] = v7.x; e[15] = v7.y;
 }
 
-// apply_update16_lds with such reads: tab_addr = LDS address of the 16-entry pair table of one pending update
+// apply_update16_lds with such reads: tab_addr = LDS address of the 16-entry pair table of one pending update, a multiple of 256
 __device__ __forceinline__ void apply_update16_asm(uint32_t w, uint32_t tab_addr, double (&e)[IPT])
 {
     d2_t v[IPT / 2];
 #pragma unroll
-    for (int s = 0; s < IPT; s += 2) v[s >> 1] = lds_read128<0>(tab_addr + (((w >> (2 * s)) & 15u) << 4));
+    for (int s = 0; s < IPT; s += 2) {
+        // entry ((w >> 2s) & 15) of a table that starts on a 256-byte boundary: the four index bits land in bits 4..7 by one
+        // shift and reach the address through an AND-OR (v_and_or_b32) instead of shift, mask, shift, add
+        const uint32_t idx16 = (2 * s >= 4) ? ((w >> (2 * s - 4)) & 0xF0u) : ((w << (4 - 2 * s)) & 0xF0u);
+        v[s >> 1] = lds_read128<0>(idx16 | tab_addr);
+    }
     lds_wait();
 #pragma unroll
     for (int s = 0; s < IPT; s += 2) {

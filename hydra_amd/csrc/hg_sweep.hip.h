@@ -125,12 +125,13 @@ __device__ __forceinline__ SweepShared sweep_lds_carve(unsigned char* base, uint
 {
     SweepShared sh;
     unsigned char* q = base;
+    // first, on a 256-byte boundary each (the streaming loop ORs the index into the address): the pending updates as tables over
+    // a pair of codes; live for the whole launch (the ahead phase streams with them after the hand-off)
+    sh.pvt = reinterpret_cast<double2*>(q); q += MAX_SEG * 16 * 16;
     sh.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
     sh.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
     sh.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
-    sh.pvt = reinterpret_cast<double2*>(q); q += MAX_SEG * 16 * 16; // the pending updates as tables over a pair of codes: live for the whole
-                                                                   // launch (the ahead phase streams with them after the hand-off)
     // the exchange buffer of the group-stage reductions (1 KiB) lies on the SECOND generator block: that one is written only by
     // the draw phase (mt_next_block), after the drawing workgroup's own group stage.  The carve-up must stay within a third of
     // a compute unit's LDS in the hardware's allocation granules (3 x 42 x 1280 B): 32 bytes more once cost a second round
@@ -873,6 +874,10 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     }
     const uint32_t nb = nbs[SEG - 1]; // all columns of this launch
     if ((nb == 0 && !pend) || d.error) return; // whole grid agrees: nothing left to do
+    if (lds_addr(hg_smem) & 255u) { // the update tables are addressed by OR: the dynamic LDS must start on a 256-byte boundary (it starts at 0)
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.desc->error = 4u;
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t voff = (uint32_t)lane << 2; // the lane's dword inside a 256-byte column piece; bases stay wave-uniform
@@ -983,13 +988,20 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
         // eps tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs, lane-linear 1 KiB pieces -- exactly the permuted
         // eps layout) one tile ahead of the arithmetic; the column dwords two tiles ahead, in registers
         unsigned char* const est = sh.estage + (size_t)wave * (TILE * sizeof(double));
-        const uint32_t est_addr = lds_addr(est), pvt_addr = lds_addr(sh.pvt);
+        const uint32_t est_addr = lds_addr(est), pvt_addr = lds_addr(sh.pvt); // (a multiple of 256: the dynamic LDS starts at 0, the table is first)
         auto dma_eps = [&](uint32_t tile) {
+            // eight 1 KiB pieces: the instruction's immediate offset (<= 4095) moves the global AND the LDS address, so two base
+            // addresses (and two M0 values) serve four pieces each
             const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
-                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const auto gp = (const __attribute__((address_space(1))) void*)(g + h2 * 512);
+                const auto lp = (__attribute__((address_space(3))) void*)(est + h2 * 4096);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+            }
         };
         // three register sets of column dwords ([0, CPG) columns, then SEG - 1 pivots, then SEG pending columns) rotate through
         // the roles "tile k" / "tile k + 1, in flight" / "free: receives tile k + 2" without a register copy (a copy would wait
@@ -1000,7 +1012,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
         // loads of the tile after it -- loads the compiler does not see would avoid that, but a register copy the allocator
         // may place at the back edge would then read a register whose load has not landed)
         auto loads = [&](uint32_t tile, uint32_t (&dst)[NLF]) {
-            const size_t off = ((size_t)tile << 8) + voff;
+            const uint32_t off = (tile << 8) + voff; // 32 bits (a column is n_pad / 4 < 2^30 bytes): scalar base + vector offset addressing
 #pragma unroll
             for (int c = 0; c < CPG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
 #pragma unroll
@@ -1135,11 +1147,17 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
         auto loads = [&](uint32_t tile, uint32_t (&dst)[SEG]) {
             const double* g = eps_in + ((size_t)tile << 10) + (lane << 1);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 128),
-                                                 (__attribute__((address_space(3))) void*)(est + k * 1024), 16, 0, 0);
+            for (int h2 = 0; h2 < 2; ++h2) { // (immediate offsets move the global and the LDS address alike: see the fresh groups)
+                const auto gp = (const __attribute__((address_space(1))) void*)(g + h2 * 512);
+                const auto lp = (__attribute__((address_space(3))) void*)(est + h2 * 4096);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+            }
+            const uint32_t off = (tile << 8) + voff;
 #pragma unroll
-            for (int q = 0; q < SEG; ++q) dst[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + ((size_t)tile << 8) + voff);
+            for (int q = 0; q < SEG; ++q) dst[q] = *reinterpret_cast<const uint32_t*>(pendp[q] + off);
         };
         if (nt) loads(tile_at(0), wp);
         stage_all();
@@ -1191,7 +1209,7 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
         for (int q = 0; q < SEG - 1; ++q) pivp[q] = (q < ng && nbs[q] > 0) ? p.bed + (size_t)p.order[d.cursor + nbs[q] - 1] * p.stride : anyp;
         uint32_t wA[NLG], wB[NLG], wC[NLG]; // three rotating register sets, as in the fresh groups
         auto loads = [&](uint32_t tile, uint32_t (&dst)[NLG]) {
-            const size_t off = ((size_t)tile << 8) + voff;
+            const uint32_t off = (tile << 8) + voff; // 32 bits (a column is n_pad / 4 < 2^30 bytes): scalar base + vector offset addressing
 #pragma unroll
             for (int c = 0; c < CCG; ++c) dst[c] = *reinterpret_cast<const uint32_t*>(colp[c] + off);
 #pragma unroll

@@ -1392,7 +1392,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->desc_host, h->desc, sizeof(SweepDesc) + sizeof(SweepCounters), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out)", dh.error, dh.cursor);
+        if (dh.error) return fail("hgibbs_sweep: device abort code %u at cursor %u (1 = logL overflow, 2 = rng staging overrun, 3 = peer exchange timed out, 4 = LDS base misaligned)", dh.error, dh.cursor);
         if (cnt_host->launches > 0) avg_accept = std::max(1.0, (double)cnt_host->accepted_sum / (double)cnt_host->launches);
         if (dh.cursor >= M && dh.pend_marker[0] < 0) break;
         // every launch accepts at least one marker or flushes a pending update: a sweep that needs more
