@@ -74,6 +74,47 @@ std::vector<std::string> tokens(const std::string& str, const std::string& sep)
     return out;
 }
 
+// Options::readFile, src/options.cpp:335-397: "key value" pairs; a key that starts with // or # skips its value token; an
+// unknown key is an error.  mcmcOut is the output prefix (directory/name); the bed file named here is read as --bfile would.
+void read_option_file(const std::string& file, Options& o)
+{
+    std::ifstream in(file.c_str());
+    if (!in) fatal("Error: can not open the file [" + file + "] to read.");
+    std::string key, value;
+    while (in >> key >> value) {
+        if (key == "bedFile") {
+            o.bedFile = value;
+            o.readFromBedFile = true;
+        } else if (key == "phenotypeFile") o.phenotypeFile = value;
+        else if (key == "analysisType") o.analysisType = value;
+        else if (key == "bayesType") o.bayesType = value;
+        else if (key == "mcmcOut") {
+            const std::string::size_type cut = value.find_last_of('/');
+            o.mcmcOutDir = cut == std::string::npos ? std::string(".") : (cut == 0 ? std::string("/") : value.substr(0, cut));
+            o.mcmcOutNam = cut == std::string::npos ? value : value.substr(cut + 1);
+        } else if (key == "shuffleMarkers") o.shuffleMarkers = std::stoi(value);
+        else if (key == "syncRate") o.syncRate = std::stoi(value);
+        else if (key == "blocksPerRank") (void)std::stoi(value); // hydra's marker-sharded MPI layout: no meaning here (individuals shard)
+        else if (key == "numberMarkers") o.numberMarkers = (unsigned)std::stoi(value);
+        else if (key == "numberIndividuals") o.numberIndividuals = (unsigned)std::stoi(value);
+        else if (key == "chainLength") o.chainLength = (unsigned)std::stoi(value);
+        else if (key == "burnin") o.burnin = (unsigned)std::stoi(value);
+        else if (key == "seed") {
+            o.seed = (unsigned)std::stoi(value);
+            o.seedGiven = true;
+        } else if (key == "thin") o.thin = (unsigned)std::stoi(value);
+        else if (key == "save") o.save = (unsigned)std::stoi(value);
+        else if (key == "S") {
+            o.S.clear();
+            for (const std::string& t : tokens(value, " ,")) o.S.push_back(std::stod(t));
+        } else if (key.substr(0, 2) == "//" || key.substr(0, 1) == "#") {
+            continue;
+        } else {
+            fatal("\nError: invalid option " + key + " " + value + "\n");
+        }
+    }
+}
+
 Options parse(int argc, const char* argv[])
 {
     Options o;
@@ -83,6 +124,11 @@ Options parse(int argc, const char* argv[])
     };
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
+        if (a == "--inp-file") { // options.cpp:8-11: the file replaces the rest of the command line
+            read_option_file(need(i), o);
+            if (!o.seedGiven) o.seed = (unsigned)std::time(nullptr);
+            return o;
+        }
         if (a == "--mpibayes" || a == "--bayesType") { // --bayesType: alias (it is the option-file key, options.cpp:353)
             o.analysisType = "RAM";
             o.bayesType = need(i);

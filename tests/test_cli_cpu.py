@@ -102,3 +102,19 @@ def test_without_a_gpu_the_run_fails_loudly(plink):
     r = run("--mpibayes", "bayesMPI", "--bfile", prefix, "--pheno", prefix + ".phen", "--mcmc-out-dir", d, "--mcmc-out-name", "n",
             "--number-individuals", "30", "--number-markers", "12", "--chain-length", "1", "--seed", "1")
     assert r.returncode != 0 and "hgibbs_create" in r.stderr
+
+
+def test_option_file_replaces_the_command_line(plink, tmp_path):
+    """--inp-file (src/options.cpp:8-11, 335-397): "key value" pairs, keys that start with # or // skip their value token,
+    an unknown key is named; the parsed options reach the same input checks as the flags do."""
+    prefix, d = plink
+    f = tmp_path / "run.opt"
+    f.write_text("bedFile %s\nphenotypeFile %s.phen\nanalysisType RAM\nbayesType bayesMPI\nmcmcOut %s/n\n"
+                 "# comment\nnumberIndividuals 31\nnumberMarkers 12\nchainLength 1\nseed 1\nS 0.1,0.01\n" % (prefix, prefix, d))
+    r = run("--inp-file", str(f))
+    assert r.returncode != 0 and "does not match the .fam file" in r.stderr  # the file's numberIndividuals (31) was read and checked
+    f.write_text("bedFile %s\nnoSuchKey 3\n" % prefix)
+    r = run("--inp-file", str(f))
+    assert r.returncode != 0 and "invalid option noSuchKey 3" in r.stderr
+    r = run("--inp-file", str(tmp_path / "absent.opt"))
+    assert r.returncode != 0 and "can not open the file" in r.stderr
