@@ -22,19 +22,18 @@
 //   beta/components/acum  M-sized, replicated on every rank.
 //
 // Kernels
-//   k_sweep_batch   the hot kernel.  One launch = [apply the pending
-//                   eps update of the previous launch's last marker] + [masked
-//                   sums S1,S2,SM of the next B markers in the shuffled order,
-//                   speculatively, against the same eps] + [the last-arriving
-//                   workgroup reduces the per-block partials in fixed order,
-//                   evaluates the mixture posterior of all B markers in
-//                   parallel, then consumes the shared MT19937 stream in marker
-//                   order and accepts markers up to and including the first one
-//                   whose effect changes (deltaBeta != 0) -- later dots are
-//                   stale and are recomputed by the next launch].  Exactly the
-//                   sequential chain: every accepted marker saw the eps the
-//                   reference's marker loop would have given it
-//                   (src/BayesRRm.cpp:1709-2025).
+//   k_sweep_batch   the hot kernel (hg_sweep.hip.h).  One launch = a speculative batch of up to 256
+//                   markers of the shuffled order, a chain of segments that end on predicted events.  Its workgroups are
+//                   the update group (applies the previous launch's events to eps, stores the other eps buffer),
+//                   Gram-only groups (carried columns: integer Gram terms with the pending columns and this launch's
+//                   pivots instead of a second pass over eps) and fresh groups (s1 = sum g nm eps against eps + pending
+//                   updates, s2 for columns with missing calls, Gram terms with the pivots).  The last workgroup of a
+//                   group sums its rows over the slices in fixed order; the last group's evaluates the mixture posterior
+//                   of a segment's markers in parallel, then consumes the shared MT19937 stream in marker order and accepts
+//                   markers up to and including the first one whose effect changes -- later dots are stale: corrected
+//                   through the Gram terms where the event was a planned pivot, else handed to the next launch as
+//                   carried columns.  Exactly the sequential chain: every accepted marker saw the eps the reference's
+//                   marker loop would have given it (src/BayesRRm.cpp:1709-2025).
 //   k_* helpers     stats, permuted get/set, scalar add, reductions, synthetic
 //                   genotypes, single-marker dot/update.
 #pragma once

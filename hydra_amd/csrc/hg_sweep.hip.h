@@ -1317,7 +1317,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     }
     __syncthreads();
 
-    bool drew = false; // this workgroup was the last arriver and ran the draw phase
     {
     // block partial = waves 0..3 in order, published write-through (sc1); this group's row block starts at group * RB
     const uint32_t rb = group * (uint32_t)RB;
@@ -1456,7 +1455,6 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     }
     sweep_draw_phase<SEG, MG, NOMISS, DBG>(p, d, nbs, sh);
     __syncthreads(); // (then on to the ahead queue like everybody else: a launch of a single workgroup has nobody else to serve it)
-    drew = true;
     }
 
     // ---- the ahead queue ---------------------------------
