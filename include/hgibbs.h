@@ -154,7 +154,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
  *   carry           hand the dots of columns behind an unplanned event to the next launch: -1 auto (default: shards of
  *                   400 000 individuals and more), 0 off, 1 on
  *   ahead           columns a launch streams ahead of its batch while its last workgroup draws, 0..256 (default 0: measured
- *                   slower on MI355X, DESIGN.md section 7; needs carry)
+ *                   slower on MI355X, DESIGN.md section 4.7; needs carry)
  *   graph           1: replay the launches from a captured HIP graph
  *   p2p, force_split, chunk, debug_timing, w_kernel_timing   transport selection and diagnostics */
 int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value);
