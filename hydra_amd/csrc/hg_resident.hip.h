@@ -1,0 +1,809 @@
+// hg_resident.hip.h -- the resident sweep engine: ONE launch per Gibbs sweep.
+//
+// The marker loop of BayesRRm::runMpiGibbs (src/BayesRRm.cpp:1709-2025) is a sequential chain: marker j+1's dot
+// needs eps after marker j's update.  The batch engine (hg_sweep.hip.h) pays a kernel launch and ~25 us of
+// N-independent hand-off latency per *event* (a marker whose effect changes).  This engine keeps the whole sweep
+// inside one kernel and shards the INDIVIDUALS over the compute units, exactly as SURVEY.md 8(e) shards them over
+// GPUs -- the compute unit is the rank:
+//
+//   * streaming workgroups (one per CU, 8 waves): workgroup w owns T wave tiles (T * 1024 individuals).  Every wave
+//     keeps the workgroup's eps slice in REGISTERS for the whole sweep (16 * T doubles per lane), so a dot product is
+//     field-extract -> int-to-f64 -> fma on registers (no LDS, no address arithmetic) and an update is 16 * T adds.
+//     The last B columns (the window) stay in LDS as 2-bit codes: the event column for the update and for the
+//     integer Gram terms x_j'x_q that correct the already-taken dots of the window (popcounts, exact).
+//   * one walker workgroup (a CU of its own, quiet memory queue): sums the per-workgroup contributions, evaluates the
+//     mixture posterior of the window's markers, consumes the shared MT19937 stream in marker order up to the first
+//     event, draws its effect (a5-a7) and broadcasts (position, dbeta) as one 16-byte message.
+//
+// Per event one round: message -> [eps update | Gram terms of the window -> atomics | dots of the columns that refill
+// the window -> atomics] -> walker.  The only cross-CU traffic of a round is ~V + 2 * ncons 8-byte atomic adds per
+// workgroup and one 16-byte message.  Sums over workgroups are integers (the Gram terms; the raw dots as 62-bit
+// fixed point), accumulated by memory-side atomic adds into words that carry their own arrival count in the top 16
+// bits: exact, order-independent (the chain does not depend on the launch geometry) and self-validating (no flag, no
+// fence).  Every spin is bounded (ResParams::timeout): a lost peer ends the sweep with error 3, never a hang.
+#pragma once
+
+#include "hg_sweep.hip.h"
+
+namespace hg {
+
+constexpr int RS_WAVES = 8;
+constexpr int RS_BLOCK = RS_WAVES * WAVE; // 512 threads: two waves per SIMD
+constexpr int RS_BMAX = 256;              // window capacity (columns kept in LDS as 2-bit codes)
+constexpr int RS_NSH = 8;                 // shards of the Gram accumulators (same-address atomics serialise at ~12 ns each)
+constexpr int RS_RSH = 4;                 // shards of the raw-dot accumulators (off the critical chain)
+constexpr int RS_RB = 2 * RS_BMAX;        // raw-dot accumulators: positions mod RS_RB
+constexpr int RS_MSG = 4;                 // message slots (seq mod RS_MSG)
+constexpr int RS_PF = 8;                  // columns one wave has in flight per streaming pass
+constexpr int RS_TMAX = 4;                // most wave tiles per workgroup
+constexpr unsigned long long RS_ONE = 1ull << 48; // arrival count lives in bits 48..63 of an accumulator word
+constexpr unsigned long long RS_LOW = RS_ONE - 1ull;
+
+enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_LAST = 8 }; // message kinds; RS_LAST is a flag bit
+
+// tag = seq << 32 | kind << 28 | ncons: the walker consumed `ncons` positions; RS_EVENT: the last of them changed its
+// effect by -dbeta (dbeta = old - new)
+struct ResMsg {
+    unsigned long long tag;
+    double dbeta;
+};
+
+struct ResState { // device -> host, written by the walker at the end of the sweep
+    uint32_t cursor, rng_idx, error, pad;
+    unsigned long long rounds, events, advances, nnz, chunks, refolds;
+    unsigned long long t[16]; // 100 MHz ticks: walker [0] fold [1] collect [2] evaluate [3] scan + draw [4] announce + outputs + prefetch;
+                              // streaming workgroup 0: [8] poll [9] update [10] Gram [11] stream
+};
+
+struct ResParams {
+    const uint8_t* bed;
+    uint64_t stride;
+    double* eps; // the current buffer, permuted layout (hg_kernels.h); updated in place at the end of the sweep
+    uint32_t n_pad, n_local, M;
+    double n_minus_1, n_total, eps_sum;
+    const int32_t* order;
+    const double* s_mave;
+    const double* s_mstd;
+    const double* s_bold;
+    const int32_t* s_ga;
+    double* beta;
+    int32_t* comp;
+    double* acum;
+    int32_t* cass;
+    int K, GK;
+    const double* denom;
+    const double* logpi;
+    const double* hlog;
+    const double* sdk;
+    double i_2sigE;
+    uint32_t* mt;
+    ZigTables zig;
+    uint32_t rng_idx;
+    uint32_t W;   // streaming workgroups; the walker is workgroup W
+    uint32_t B;   // window (power of two, <= RS_BMAX, B * T <= 512)
+    uint32_t nsh, rsh;
+    unsigned long long* gacc; // [2][RS_NSH][RS_BMAX]
+    unsigned long long* racc; // [RS_RSH][RS_RB][2]
+    ResMsg* msg;              // [RS_MSG]
+    ResState* state;
+    double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale) (62-bit fixed point)
+    unsigned long long timeout;  // 100 MHz ticks a spin may last
+    int dbg;
+};
+
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4_t rs_load16(const void* p)
+{
+    u4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void rs_store16(void* p, u4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    u4_t v;
+    v.x = x;
+    v.y = y;
+    v.z = z;
+    v.w = w;
+    return v;
+}
+
+__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 16 + (size_t)B * 256 * T; }
+__host__ __device__ inline size_t rs_walker_lds(uint32_t B)
+{
+    return (size_t)MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + (size_t)B * (6 * 8 + 2 * 4 + 1) + 16 + (size_t)RS_BLOCK * 9 + 64 * 8 + 64 * 4 + 256 * 4 + 256;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// streaming workgroup
+// ---------------------------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void rs_load_col(const uint8_t* col, uint32_t voff, uint32_t (&w)[T])
+{
+    if constexpr (T == 1) {
+        w[0] = *reinterpret_cast<const uint32_t*>(col + voff);
+    } else if constexpr (T == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(col + voff);
+        w[0] = v.x;
+        w[1] = v.y;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(col + voff);
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+    }
+}
+
+template <int T, int DBG>
+__device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wg = blockIdx.x;
+    const uint32_t B = p.B, bmask = B - 1u, M = p.M;
+    double2* const tab = reinterpret_cast<double2*>(smem);                        // pair table of the event's addends (256 B)
+    unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
+    double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 16); // [B][64 * T] codes of the window columns
+    const bool timing = DBG && wg == 0 && tid == 0;
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
+    auto lap = [&](int i) {
+        if (timing) {
+            const unsigned long long now = wall_clock64();
+            tacc[i] += now - tmark;
+            tmark = now;
+        }
+    };
+
+    // this lane's T dwords of every column: dwords [d0, d0 + T) = individuals [16 d0, 16 (d0 + T)) of the shard
+    const uint32_t d0 = (wg * 64u + (uint32_t)lane) * (uint32_t)T;
+    const uint32_t ndw = p.n_pad >> 4;
+    const bool vgrp = d0 < ndw; // T divides ndw (a multiple of 256): all of the lane's dwords or none
+    const uint32_t voff = vgrp ? d0 * 4u : 0u;
+    uint32_t keep[T];
+    double e[T][IPT];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t i0 = (d0 + (uint32_t)t) * 16u;
+        const uint32_t nv = (!vgrp || i0 >= p.n_local) ? 0u : (p.n_local - i0 >= 16u ? 16u : p.n_local - i0);
+        keep[t] = nv >= 16u ? 0xffffffffu : ((1u << (2u * nv)) - 1u);
+#pragma unroll
+        for (int s = 0; s < IPT; ++s) e[t][s] = vgrp ? p.eps[eps_pos(i0 + (uint32_t)s)] : 0.0;
+    }
+
+    uint32_t C = 0, Sx = 0, seq = 0, nev = 0;
+    uint32_t kind = RS_ADVANCE, ncons = 0;
+    bool last = M == 0;
+    double dbeta = 0.0;
+    for (;;) {
+        const bool upd = kind == RS_EVENT;
+        const uint32_t q = C + ncons - 1u;
+        const uint32_t Cn = C + ncons;
+        const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
+        const uint32_t nnew = Sn - Sx;
+        const uint32_t first = Sx + (uint32_t)wave;
+        const uint32_t count_w = nnew > (uint32_t)wave ? (nnew - (uint32_t)wave + 7u) / 8u : 0u; // positions first + 8 k
+
+        uint32_t cw[RS_PF][T];
+        auto issue = [&](uint32_t k0) {
+#pragma unroll
+            for (int k = 0; k < RS_PF; ++k) {
+                if (k0 + (uint32_t)k < count_w) {
+                    const uint32_t pos = __builtin_amdgcn_readfirstlane(first + 8u * (k0 + (uint32_t)k));
+                    const int32_t mk = p.order[pos];
+                    rs_load_col<T>(p.bed + (size_t)mk * p.stride, voff, cw[k]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) cw[k][t] = 0u;
+                }
+            }
+        };
+        issue(0u); // the refill's first columns are on their way from HBM while the event is applied
+
+        if (upd) {
+            // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave ----
+            const uint32_t slotq = q & bmask;
+            uint32_t xq[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xq[t] = ring[slotq * 64u * T + (uint32_t)lane * T + t];
+            const double2 mq = meta[slotq];
+            if (tid < 16) {
+                const double av = mq.x, sd = mq.y, db = dbeta;
+                const double v0 = -(av * sd * db), v1 = db * (1.0 - av) * sd, v2 = db * (2.0 - av) * sd;
+                auto addend = [&](uint32_t c) { return 0.0 + ((c == GC_G0) ? v0 : ((c == GC_G1) ? v1 : ((c == GC_G2) ? v2 : 0.0))); };
+                tab[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
+            lap(1);
+
+            // ---- integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind q (their dots were taken before this
+            // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
+            const uint32_t V = Sx - (q + 1u);
+            const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
+            GramPivot gp[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) gp[t] = gram_pivot(xq[t]);
+            uint32_t acc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0u;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                if ((uint32_t)c < Vw && i0 + (uint32_t)c < V) { // wave-uniform
+                    const uint32_t slot = (q + 1u + i0 + (uint32_t)c) & bmask;
+                    const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+                    uint32_t g = 0u;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) g += gram16x(gram_xform(rp[t]), gp[t]);
+                    acc[c >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
+                }
+            }
+            uint32_t mine = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((uint32_t)(2 * r) < Vw) { // wave-uniform
+                    const uint32_t tot = wave_sum_u32(acc[r]);
+                    mine = (lane == 2 * r) ? (tot & 0xffffu) : ((lane == 2 * r + 1) ? (tot >> 16) : mine);
+                }
+            }
+            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
+                unsigned long long* a = p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_BMAX + i0 + (uint32_t)lane;
+                __hip_atomic_fetch_add(a, RS_ONE | (unsigned long long)mine, HG_RLX_AGENT);
+            }
+            ++nev;
+            lap(2);
+        }
+
+        // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
+        for (uint32_t k0 = 0; k0 < count_w; k0 += RS_PF) {
+            if (k0) issue(k0);
+#pragma unroll
+            for (int g = 0; g < RS_PF / 4; ++g) {
+                if (k0 + 4u * g < count_w) { // wave-uniform
+                    double a[4] = {0.0, 0.0, 0.0, 0.0};
+                    uint32_t gw[4][T];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) gw[c][t] = cw[4 * g + c][t] & keep[t];
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        fma_slots4(gw[0][t], gw[1][t], gw[2][t], gw[3][t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT>{});
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t kk = k0 + 4u * g + (uint32_t)c;
+                        if (kk < count_w) { // wave-uniform
+                            const uint32_t pos = __builtin_amdgcn_readfirstlane(first + 8u * kk);
+                            const uint32_t slot = pos & bmask;
+                            uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+#pragma unroll
+                            for (int t = 0; t < T; ++t) rp[t] = gw[c][t];
+                            if (lane == 0) meta[slot] = make_double2(p.s_mave[pos], p.s_mstd[pos]);
+                            const double s1 = wave_sum(a[c]);
+                            const double sc = s1 * p.fx_scale;
+                            if (!(fabs(sc) < 4.0e18)) { // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
+                                if (lane == 0) atomicMax(&p.state->error, 5u);
+                            }
+                            const long long v = __double2ll_rn(sc);
+                            const unsigned long long lo = (unsigned long long)(uint32_t)v;
+                            const unsigned long long hi = (unsigned long long)(uint32_t)((v >> 32) + 0x80000000ll);
+                            if (lane < 2) {
+                                unsigned long long* a2 = p.racc + (((size_t)(wg % p.rsh) * RS_RB + (pos % RS_RB)) << 1) + (uint32_t)lane;
+                                __hip_atomic_fetch_add(a2, RS_ONE | (lane ? hi : lo), HG_RLX_AGENT);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        lap(3);
+        __syncthreads(); // the window's new columns are in LDS for every wave
+        C = Cn;
+        Sx = Sn;
+        if (last) break;
+
+        // ---- wait for the walker's next message (one lane polls; everybody else sleeps at the barrier) ----
+        ++seq;
+        if (tid == 0) {
+            const ResMsg* m = p.msg + (seq % RS_MSG);
+            const unsigned long long t0 = wall_clock64();
+            u4_t v;
+            for (;;) {
+                v = rs_load16(m);
+                if (v.y == seq) break;
+                if (wall_clock64() - t0 > p.timeout) {
+                    v.x = (uint32_t)RS_ABORT << 28;
+                    v.y = seq;
+                    atomicMax(&p.state->error, 3u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            lmsg[0] = ((unsigned long long)v.y << 32) | v.x;
+            lmsg[1] = ((unsigned long long)v.w << 32) | v.z;
+        }
+        __syncthreads();
+        const unsigned long long tag = lmsg[0];
+        dbeta = __longlong_as_double((long long)lmsg[1]);
+        const uint32_t kf = (uint32_t)(tag >> 28) & 0xfu;
+        kind = kf & 7u;
+        last = (kf & RS_LAST) != 0u;
+        ncons = (uint32_t)tag & 0x0fffffffu;
+        lap(0);
+        if (kind == RS_ABORT) break;
+    }
+
+    // eps goes back to HBM in the layout the other kernels read (padding slots stay zero)
+    if (wave == 0 && vgrp) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint32_t i0 = (d0 + (uint32_t)t) * 16u;
+#pragma unroll
+            for (int s = 0; s < IPT; ++s) p.eps[eps_pos(i0 + (uint32_t)s)] = (i0 + (uint32_t)s < p.n_local) ? e[t][s] : 0.0;
+        }
+    }
+    if (timing)
+        for (int i = 0; i < 4; ++i) p.state->t[8 + i] = tacc[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// walker workgroup
+// ---------------------------------------------------------------------------------------------------------------
+struct WalkShared {
+    uint32_t* mt;
+    double *zig_nx, *zig_ny, *htab;
+    double *mave, *mstd, *bold, *dp, *thr0, *num; // window slots
+    int32_t *marker, *grp;
+    uint8_t* ada;
+    double* ebuf;   // [RS_BLOCK] exp(logL_l - logL_0) of the chunk under evaluation
+    uint8_t* bigf;  // [RS_BLOCK]
+    double* fd;     // 64 doubles of scratch (event: dbeta, bnew, prob, ...)
+    uint32_t* fl;   // 64 words of flags
+    int32_t* lcass; // [256]
+};
+enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_NADA = 6 };
+enum { WD_DBETA = 0, WD_BNEW = 1, WD_PROB = 2 };
+
+__device__ __forceinline__ WalkShared walk_carve(unsigned char* q, uint32_t B)
+{
+    WalkShared s;
+    s.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
+    s.zig_nx = reinterpret_cast<double*>(q); q += 130 * 8;
+    s.zig_ny = reinterpret_cast<double*>(q); q += 130 * 8;
+    s.htab = reinterpret_cast<double*>(q); q += (size_t)4 * HT_LDS * 8;
+    s.mave = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.mstd = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.bold = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.dp = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.thr0 = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.num = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.ebuf = reinterpret_cast<double*>(q); q += (size_t)RS_BLOCK * 8;
+    s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
+    s.marker = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
+    s.grp = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
+    s.fl = reinterpret_cast<uint32_t*>(q); q += 64 * 4;
+    s.lcass = reinterpret_cast<int32_t*>(q); q += 256 * 4;
+    s.bigf = q; q += RS_BLOCK;
+    s.ada = q;
+    return s;
+}
+
+template <int DBG>
+__device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t B = p.B, bmask = B - 1u, M = p.M;
+    const int K = p.K;
+    const bool lds_tab = p.GK <= HT_LDS;
+    const WalkShared sh = walk_carve(smem, B);
+    const uint32_t EV = (uint32_t)RS_BLOCK / (uint32_t)K; // markers evaluated per chunk: one thread per (marker, component)
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tmark = DBG ? wall_clock64() : 0ull;
+    auto lap = [&](int i) {
+        if (DBG && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            tacc[i] += now - tmark;
+            tmark = now;
+        }
+    };
+
+    // generator, tables, counters
+    for (int i = tid; i < MT_N; i += RS_BLOCK) sh.mt[i] = p.mt[i];
+    for (int i = tid; i < 129; i += RS_BLOCK) {
+        sh.zig_nx[i] = p.zig.nx[i];
+        sh.zig_ny[i] = p.zig.ny[i];
+    }
+    if (lds_tab)
+        for (int i = tid; i < 4 * p.GK; i += RS_BLOCK) sh.htab[(i / p.GK) * HT_LDS + (i % p.GK)] = p.denom[i];
+    for (int i = tid; i < 256; i += RS_BLOCK) sh.lcass[i] = 0;
+    if (tid < 64) sh.fl[tid] = 0u;
+    auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
+        if (lds_tab) return sh.htab[which * HT_LDS + t];
+        return which == 0 ? p.denom[t] : (which == 1 ? p.logpi[t] : (which == 2 ? p.hlog[t] : p.sdk[t]));
+    };
+
+    // window slots of the positions [lo, hi): per-marker metadata, dot accumulator reset
+    auto prefetch = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t j = lo + (uint32_t)tid; j < hi; j += RS_BLOCK) {
+            const uint32_t slot = j & bmask;
+            const int ga = p.s_ga[j];
+            sh.marker[slot] = p.order[j];
+            sh.grp[slot] = ga & 0x0fffffff;
+            sh.ada[slot] = (uint8_t)((ga & 0x40000000) ? 1 : 0);
+            sh.bold[slot] = p.s_bold[j];
+            sh.mave[slot] = p.s_mave[j];
+            sh.mstd[slot] = p.s_mstd[j];
+            sh.dp[slot] = 0.0;
+        }
+    };
+
+    uint32_t cntG[RS_NSH], cntR[RS_RSH];
+#pragma unroll
+    for (int s = 0; s < RS_NSH; ++s) cntG[s] = (uint32_t)s < p.nsh ? p.W / p.nsh + ((uint32_t)s < p.W % p.nsh ? 1u : 0u) : 0u;
+#pragma unroll
+    for (int s = 0; s < RS_RSH; ++s) cntR[s] = (uint32_t)s < p.rsh ? p.W / p.rsh + ((uint32_t)s < p.W % p.rsh ? 1u : 0u) : 0u;
+
+    uint32_t C = 0, Sx = (B < M) ? B : M, SxPrev = Sx, F = 0, rpos = p.rng_idx, seq = 0, nev = 0;
+    bool has_next = false, aborted = false;
+    bool pendG = false;
+    uint32_t gq = 0, gV = 0;          // the event whose Gram terms are still to be collected: position, window columns behind it
+    double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0;
+    unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0;
+    prefetch(0u, Sx);
+    __syncthreads();
+
+    // raw dots of the positions [F, hi): sum of the workgroups' fixed-point contributions -> s1 -> x_j'eps
+    auto fold = [&](uint32_t hi) {
+        for (uint32_t j = F + (uint32_t)tid; j < hi; j += RS_BLOCK) {
+            const uint32_t slot = j & bmask;
+            unsigned long long* base = p.racc + ((size_t)(j % RS_RB) << 1);
+            unsigned long long w[RS_RSH][2];
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int s = 0; s < RS_RSH; ++s) {
+                    if ((uint32_t)s < p.rsh) {
+                        w[s][0] = __hip_atomic_load(base + (size_t)s * RS_RB * 2, HG_RLX_AGENT);
+                        w[s][1] = __hip_atomic_load(base + (size_t)s * RS_RB * 2 + 1, HG_RLX_AGENT);
+                    } else {
+                        w[s][0] = w[s][1] = 0ull;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < RS_RSH; ++s) ok = ok && (uint32_t)(w[s][0] >> 48) == cntR[s] && (uint32_t)(w[s][1] >> 48) == cntR[s];
+                if (ok) break;
+                if (wall_clock64() - t0 > p.timeout) {
+                    sh.fl[WF_ABORT] = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            unsigned long long slo = 0ull, shi = 0ull;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) {
+                slo += w[s][0] & RS_LOW;
+                shi += w[s][1] & RS_LOW;
+                if ((uint32_t)s < p.rsh) { // free for position j + RS_RB (streamed only after a later message: the stores are drained before every message)
+                    __hip_atomic_store(base + (size_t)s * RS_RB * 2, 0ull, HG_RLX_AGENT);
+                    __hip_atomic_store(base + (size_t)s * RS_RB * 2 + 1, 0ull, HG_RLX_AGENT);
+                }
+            }
+            const long long hi_sum = (long long)shi - (long long)p.W * 0x80000000ll;
+            const long long tot = (long long)((unsigned long long)hi_sum << 32) + (long long)slo;
+            const double s1 = (double)tot * p.fx_unscale;
+            sh.dp[slot] += sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
+        }
+        if (hi > F) F = hi;
+    };
+
+    for (;;) {
+        if (C >= M) break;
+        ++n_rounds;
+        // generator: the next block exists before a round can run into it
+        if (!has_next && rpos + B + 96u > (uint32_t)MT_N) {
+            mt_next_block(sh.mt, tid);
+            has_next = true;
+        }
+        // 1. dots of everything streamed before the last message
+        fold(SxPrev);
+        __syncthreads(); // (a slot may get its dot from one thread and its correction from another)
+        lap(0);
+        // 2. Gram corrections of the last event for the window columns behind it
+        if (pendG) {
+            if ((uint32_t)tid < gV) {
+                unsigned long long* base = p.gacc + (size_t)((nev - 1u) & 1u) * RS_NSH * RS_BMAX + (uint32_t)tid;
+                unsigned long long w[RS_NSH];
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int s = 0; s < RS_NSH; ++s) w[s] = (uint32_t)s < p.nsh ? __hip_atomic_load(base + (size_t)s * RS_BMAX, HG_RLX_AGENT) : 0ull;
+#pragma unroll
+                    for (int s = 0; s < RS_NSH; ++s) ok = ok && (uint32_t)(w[s] >> 48) == cntG[s];
+                    if (ok) break;
+                    if (wall_clock64() - t0 > p.timeout) {
+                        sh.fl[WF_ABORT] = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                unsigned long long A = 0ull;
+#pragma unroll
+                for (int s = 0; s < RS_NSH; ++s) {
+                    A += w[s] & RS_LOW;
+                    if ((uint32_t)s < p.nsh) __hip_atomic_store(base + (size_t)s * RS_BMAX, 0ull, HG_RLX_AGENT);
+                }
+                const uint32_t slot = (gq + 1u + (uint32_t)tid) & bmask;
+                const double mj = sh.mave[slot], sj = sh.mstd[slot];
+                const double xx = sj * g_mstd * ((double)A - p.n_total * (mj * g_mave));
+                sh.dp[slot] += g_db * xx;
+            }
+            pendG = false;
+        }
+        __syncthreads();
+        lap(1);
+        if (sh.fl[WF_ABORT]) {
+            aborted = true;
+            break;
+        }
+
+        // 3. the walk: posterior of a chunk of markers in parallel, then wave 0 consumes the stream in marker order
+        uint32_t base = C;
+        bool found = false;
+        while (!found && base < Sx) {
+            const uint32_t nevl = (Sx - base < EV) ? Sx - base : EV;
+            if (base + nevl > F) { // reaches into the columns streamed behind the last message: their dots are needed now
+                ++n_refold;
+                fold(base + nevl);
+                __syncthreads();
+                if (sh.fl[WF_ABORT]) break;
+            }
+            ++n_chunks;
+            {
+                const uint32_t jj = (uint32_t)tid / (uint32_t)K;
+                const int l = (int)((uint32_t)tid % (uint32_t)K);
+                if (jj < nevl) {
+                    const uint32_t slot = (base + jj) & bmask;
+                    if (sh.ada[slot]) {
+                        const int g0 = sh.grp[slot] * K;
+                        const double num = sh.dp[slot] + sh.bold[slot] * p.n_minus_1;
+                        const double L0 = tabv(1, g0);
+                        double L = L0;
+                        if (l > 0) {
+                            const double mk = num / tabv(0, g0 + l);
+                            L = tabv(1, g0 + l) - tabv(2, g0 + l) + mk * num * p.i_2sigE;
+                        }
+                        const double d = L - L0;
+                        sh.ebuf[tid] = exp(d);
+                        sh.bigf[tid] = (uint8_t)((l >= 1 && fabs(d) > 700.0) ? 1 : 0);
+                        if (l == 0) sh.num[slot] = num;
+                    }
+                }
+            }
+            __syncthreads();
+            if ((uint32_t)tid < nevl) {
+                const uint32_t slot = (base + (uint32_t)tid) & bmask;
+                if (sh.ada[slot]) {
+                    double sum = 0.0;
+                    bool big = false;
+                    for (int l = 0; l < K; ++l) {
+                        sum += sh.ebuf[(uint32_t)tid * (uint32_t)K + (uint32_t)l];
+                        big = big || sh.bigf[(uint32_t)tid * (uint32_t)K + (uint32_t)l] != 0;
+                    }
+                    sh.thr0[slot] = big ? 0.0 : 1.0 / sum;
+                }
+            }
+            __syncthreads();
+            lap(2);
+
+            if (tid < WAVE) {
+                uint32_t pos = rpos, fq = 0u;
+                double fprob = 0.0;
+                bool stopped = false;
+                for (uint32_t cb = 0; cb < nevl && !stopped; cb += WAVE) {
+                    const bool valid = cb + (uint32_t)lane < nevl;
+                    const uint32_t slot = (base + cb + (uint32_t)lane) & bmask;
+                    const bool ada = valid && sh.ada[slot] != 0;
+                    const double bold = valid ? sh.bold[slot] : 0.0;
+                    const unsigned long long am = __ballot(ada);
+                    const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    double prob = 0.0;
+                    bool ev = valid && bold != 0.0;
+                    if (ada) {
+                        const uint32_t u = mt_temper(sh.mt[pos + jeff]);
+                        prob = (double)u * (1.0 / 4294967296.0);
+                        ev = ev || !(prob <= sh.thr0[slot]);
+                    }
+                    const unsigned long long em = __ballot(ev);
+                    const uint32_t nvalid = (nevl - cb < (uint32_t)WAVE) ? nevl - cb : (uint32_t)WAVE;
+                    if (em) {
+                        const uint32_t f = (uint32_t)(__ffsll((long long)em) - 1);
+                        const uint32_t used = (uint32_t)__popcll(am & ((f >= 63u) ? ~0ull : ((1ull << (f + 1u)) - 1ull)));
+                        pos += used;
+                        stopped = true;
+                        fq = base + cb + f;
+                        fprob = __shfl(prob, (int)f, 64);
+                    } else {
+                        pos += (uint32_t)__popcll(am & ((nvalid >= 64u) ? ~0ull : ((1ull << nvalid) - 1ull)));
+                    }
+                }
+                // the event: all thresholds of its marker (:1883-1921), the component, the draw (a7)
+                if (stopped) {
+                    const uint32_t slot = fq & bmask;
+                    const bool ada = sh.ada[slot] != 0;
+                    const double bold = sh.bold[slot], prob = fprob;
+                    int k = 0;
+                    double bnew = 0.0;
+                    uint32_t consumed = 0u, gerr = 0u;
+                    if (ada && !(prob <= sh.thr0[slot])) { // wave-uniform
+                        const int g0 = sh.grp[slot] * K;
+                        const double num = sh.num[slot];
+                        double Lm = 0.0; // lane x < K: logL_x
+                        if (lane < K) {
+                            Lm = tabv(1, g0 + lane);
+                            if (lane > 0) {
+                                const double mk = num / tabv(0, g0 + lane);
+                                Lm = tabv(1, g0 + lane) - tabv(2, g0 + lane) + mk * num * p.i_2sigE;
+                            }
+                        }
+                        const int kk = lane >> 3, l = lane & 7;
+                        const double Ll = __shfl(Lm, l, 64), Lk = __shfl(Lm, kk, 64);
+                        const bool on = kk < K - 1 && l < K;
+                        const double d = on ? Ll - Lk : 0.0;
+                        const double ex = exp(d);
+                        const bool bigp = on && l >= (kk ? kk : 1) && fabs(d) > 700.0;
+                        const unsigned long long bm = __ballot(bigp);
+                        double sum = 0.0;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            const double v = __shfl(ex, (lane & ~7) + x, 64);
+                            if (x < K) sum += v;
+                        }
+                        const bool anyb = ((bm >> (lane & ~7)) & 0xffull) != 0ull;
+                        const double thr = anyb ? 0.0 : 1.0 / sum; // of walk step kk, the same value in the 8 lanes of its group
+                        k = K - 1;
+                        double acum = 0.0;
+                        bool fnd = false;
+                        for (int s = 0; s + 1 < K; ++s) {
+                            const double t = __shfl(thr, 8 * s, 64);
+                            acum = s ? acum + t : t;
+                            if (!fnd && prob <= acum) {
+                                k = s;
+                                fnd = true;
+                            }
+                        }
+                        if (lane == 0 && k > 0) {
+                            LdsGen g{sh.mt, pos, has_next ? (uint32_t)MT_BUF : (uint32_t)MT_N, 0u};
+                            ZigTables zt{sh.zig_nx, sh.zig_ny, p.zig.ex, p.zig.ey};
+                            bnew = norm_rng_sd(g, zt, num / tabv(0, g0 + k), tabv(3, g0 + k));
+                            consumed = g.pos - pos;
+                            gerr = g.err;
+                        }
+                        bnew = __shfl(bnew, 0, 64);
+                        consumed = (uint32_t)__shfl((int)consumed, 0, 64);
+                        gerr = (uint32_t)__shfl((int)gerr, 0, 64);
+                    }
+                    pos += consumed;
+                    if (lane == 0) {
+                        sh.fl[WF_FOUND] = 1u;
+                        sh.fl[WF_Q] = fq;
+                        sh.fl[WF_K] = (uint32_t)k;
+                        sh.fd[WD_BNEW] = bnew;
+                        sh.fd[WD_DBETA] = bold - bnew;
+                        if (gerr) sh.fl[WF_ERR] = gerr;
+                    }
+                }
+                if (lane == 0) sh.fl[WF_RPOS] = pos;
+            }
+            __syncthreads();
+            rpos = sh.fl[WF_RPOS];
+            found = sh.fl[WF_FOUND] != 0u;
+            if (!found) base += nevl;
+            lap(3);
+        }
+        if (sh.fl[WF_ABORT] || sh.fl[WF_ERR]) {
+            aborted = true;
+            break;
+        }
+
+        // 4. the message
+        const uint32_t qpos = found ? sh.fl[WF_Q] : 0u;
+        const uint32_t ncons = found ? qpos - C + 1u : Sx - C;
+        const double dbeta = found ? sh.fd[WD_DBETA] : 0.0, bnew = found ? sh.fd[WD_BNEW] : 0.0;
+        const int kq = found ? (int)sh.fl[WF_K] : 0;
+        const bool is_event = found && dbeta != 0.0;
+        const uint32_t Cn = C + ncons;
+        const bool lastmsg = Cn >= M;
+        wait_vmcnt<0>(); // this wave's zeroing stores have landed ...
+        __syncthreads(); // ... and everybody else's
+        ++seq;
+        if (tid == 0) {
+            const uint32_t kf = (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE) | (lastmsg ? (uint32_t)RS_LAST : 0u);
+            const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
+            rs_store16(p.msg + (seq % RS_MSG), rs_u4((kf << 28) | ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)));
+        }
+        if (is_event) {
+            const uint32_t slot = qpos & bmask;
+            pendG = true;
+            gq = qpos;
+            gV = Sx - (qpos + 1u);
+            g_db = dbeta;
+            g_mave = sh.mave[slot];
+            g_mstd = sh.mstd[slot];
+            ++nev;
+            ++n_events;
+            ++n_nnz;
+        } else {
+            ++n_adv;
+        }
+
+        // 5. results of the consumed markers (:1892,:1899-1905,:1924-1925), then their slots go to the refill
+        for (uint32_t j = C + (uint32_t)tid; j < Cn; j += RS_BLOCK) {
+            const uint32_t slot = j & bmask;
+            const int marker = sh.marker[slot];
+            const bool isq = found && j == qpos;
+            if (sh.ada[slot]) {
+                const int kk = isq ? kq : 0;
+                p.beta[marker] = isq ? bnew : 0.0;
+                p.comp[marker] = kk;
+                p.acum[marker] = sh.thr0[slot];
+                atomicAdd(&sh.lcass[sh.grp[slot] * K + kk], 1);
+            } else {
+                p.beta[marker] = 0.0;
+                p.acum[marker] = 1.0;
+            }
+        }
+        if (tid == 0) {
+            sh.fl[WF_FOUND] = 0u;
+        }
+        __syncthreads();
+        const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
+        prefetch(Sx, Sn);
+        if (rpos >= (uint32_t)MT_N) { // the stream crossed into the next block: it becomes the current one
+            for (int i = tid; i < MT_N; i += RS_BLOCK) sh.mt[i] = sh.mt[MT_N + i];
+            rpos -= (uint32_t)MT_N;
+            has_next = false;
+        }
+        __syncthreads();
+        SxPrev = Sx;
+        Sx = Sn;
+        C = Cn;
+        lap(4);
+    }
+
+    if (aborted) {
+        ++seq;
+        if (tid == 0) {
+            rs_store16(p.msg + (seq % RS_MSG), rs_u4((uint32_t)RS_ABORT << 28, seq, 0u, 0u));
+            atomicMax(&p.state->error, sh.fl[WF_ERR] ? sh.fl[WF_ERR] : 3u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT_N; i += RS_BLOCK) p.mt[i] = sh.mt[i];
+    for (int i = tid; i < p.GK; i += RS_BLOCK) p.cass[i] = sh.lcass[i];
+    if (tid == 0) {
+        ResState* st = p.state;
+        st->cursor = C;
+        st->rng_idx = rpos;
+        st->rounds = n_rounds;
+        st->events = n_events;
+        st->advances = n_adv;
+        st->nnz = n_nnz;
+        st->chunks = n_chunks;
+        st->refolds = n_refold;
+        if (DBG)
+            for (int i = 0; i < 5; ++i) st->t[i] = tacc[i];
+    }
+}
+
+template <int T, int DBG>
+__global__ __launch_bounds__(RS_BLOCK) void k_sweep_resident(ResParams p)
+{
+    if (blockIdx.x < p.W) res_streamer<T, DBG>(p, hg_smem);
+    else res_walker<DBG>(p, hg_smem);
+}
+
+} // namespace hg

@@ -16,6 +16,7 @@
 #include "../../include/hgibbs.h"
 #include "hg_kernels.h"
 #include "hg_sweep.hip.h"
+#include "hg_resident.hip.h"
 
 using namespace hg;
 
@@ -141,6 +142,16 @@ struct hgibbs_ctx {
     bool use_graph = false; // replay the sweep's launches from a captured graph
     bool force_split = false; // run dots -> all-reduce -> draw as separate launches even on one rank
 
+    // resident engine (hg_resident.hip.h): one launch per sweep, individuals sharded over the compute units
+    int engine = 0;           // option engine: 0 auto (resident where it applies), 1 batch engine (k_sweep_batch), 2 resident (refused where it does not apply)
+    uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
+    uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
+    unsigned long long* res_acc = nullptr; // Gram + raw-dot accumulators
+    ResMsg* res_msg = nullptr;
+    ResState* res_state = nullptr;
+    ResState* res_state_host = nullptr; // pinned
+    double res_timeout_s = 2.0;
+
     hgibbs_sweep_stats stats{};
 };
 
@@ -153,6 +164,8 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
     return 0;
 }
 
+static constexpr size_t RES_GACC_WORDS = (size_t)2 * RS_NSH * RS_BMAX, RES_RACC_WORDS = (size_t)RS_RSH * RS_RB * 2;
+static constexpr size_t RES_ACC_WORDS = RES_GACC_WORDS + RES_RACC_WORDS;
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
 static constexpr size_t MBOX_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long);
 
@@ -550,6 +563,10 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMalloc(&h->dbg, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->res_acc, RES_ACC_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->res_msg, RS_MSG * sizeof(ResMsg)));
+    HIP_TRY(hipMalloc(&h->res_state, sizeof(ResState)));
+    HIP_TRY(hipHostMalloc(&h->res_state_host, sizeof(ResState)));
     *out = h;
     return 0;
 }
@@ -565,11 +582,12 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket, h->res_acc, h->res_msg, h->res_state};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
     if (h->scratch_host) (void)hipHostFree(h->scratch_host);
+    if (h->res_state_host) (void)hipHostFree(h->res_state_host);
     if (h->beta_host) (void)hipHostFree(h->beta_host);
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
@@ -1096,6 +1114,18 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         if (value < -1 || value > AHEAD_MAX) return fail("ahead must be in [-1,%d] (-1 = auto)", AHEAD_MAX);
         h->ahead = (int)value;
 
+    } else if (!std::strcmp(name, "engine")) {
+        if (value < 0 || value > 2) return fail("engine must be 0 (auto), 1 (batch) or 2 (resident)");
+        h->engine = (int)value;
+    } else if (!std::strcmp(name, "window")) {
+        if (value != 0 && (value < 8 || value > RS_BMAX || (value & (value - 1)))) return fail("window must be 0 (auto) or a power of two in [8,%d]", RS_BMAX);
+        h->window = (uint32_t)value;
+    } else if (!std::strcmp(name, "res_cus")) {
+        if (value < 0 || value > 4096) return fail("res_cus must be in [0,4096]");
+        h->res_cus = (uint32_t)value;
+    } else if (!std::strcmp(name, "res_timeout_ms")) {
+        if (value < 1) return fail("res_timeout_ms must be positive");
+        h->res_timeout_s = (double)value * 1e-3;
     } else if (!std::strcmp(name, "p2p")) {
         h->p2p_enabled = value != 0;
     } else if (!std::strcmp(name, "force_split")) {
@@ -1151,6 +1181,163 @@ int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out)
     *out = h->stats;
     return 0;
 }
+
+} // extern "C"
+
+// ---- the resident engine (hg_resident.hip.h) -------------------------------------------------------------------
+struct ResPlan {
+    bool ok = false;
+    int T = 1;        // wave tiles per streaming workgroup
+    uint32_t W = 0;   // streaming workgroups (+ 1 walker)
+    uint32_t B = 0;   // window
+};
+
+// nullptr when the resident engine can run this handle's sweeps, else the reason why not
+static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
+{
+    pl->ok = false;
+    if (h->nranks > 1) return "several ranks (the exchange lives in the batch engine)";
+    if (h->force_split) return "force_split";
+    if (h->any_missing) return "columns with missing calls";
+    if (h->G * h->K > 256 || h->K > MAX_K || h->K < 2) return "mixture size";
+    const uint32_t cus = h->res_cus ? std::min<uint32_t>(h->res_cus, (uint32_t)h->num_cu) : (uint32_t)h->num_cu;
+    if (cus < 2) return "fewer than two compute units";
+    const uint32_t ntile = h->n_pad / TILE;
+    uint32_t T = (ntile + (cus - 1) - 1) / (cus - 1);
+    T = T <= 1 ? 1 : (T <= 2 ? 2 : 4);
+    if ((uint64_t)T * (cus - 1) < ntile) return "more individuals than RS_TMAX tiles per compute unit hold";
+    pl->T = (int)T;
+    pl->W = (ntile + T - 1) / T;
+    uint32_t B = h->window ? h->window : (uint32_t)RS_BMAX;
+    while (B * T > 512u) B >>= 1;
+    pl->B = B;
+    pl->ok = true;
+    return nullptr;
+}
+
+static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
+{
+    const int G = h->G, K = h->K;
+    double r0[2];
+    if (reduce_eps_all(h, r0)) return 1; // (sum, sum of squares) over all individuals
+    ResParams p{};
+    p.bed = h->bed;
+    p.stride = h->stride;
+    p.eps = h->eps[h->eps_cur];
+    p.n_pad = h->n_pad;
+    p.n_local = h->n_local;
+    p.M = h->M;
+    p.n_minus_1 = (double)(h->n_global - 1);
+    p.n_total = (double)h->n_global;
+    p.eps_sum = r0[0]; // s2 of every column (none has missing calls here), see hgibbs_sweep
+    p.order = h->order;
+    p.s_mave = h->s_mave;
+    p.s_mstd = h->s_mstd;
+    p.s_bold = h->s_bold;
+    p.s_ga = h->s_ga;
+    p.beta = h->beta;
+    p.comp = h->comp;
+    p.acum = h->acum;
+    p.cass = h->cass;
+    p.K = K;
+    p.GK = G * K;
+    p.denom = h->tables;
+    p.logpi = h->tables + (size_t)G * K;
+    p.hlog = h->tables + (size_t)2 * G * K;
+    p.sdk = h->tables + (size_t)3 * G * K;
+    p.i_2sigE = 1.0 / (2.0 * sigmaE);
+    p.mt = h->mt;
+    p.zig = ZigTables{h->zig, h->zig + 129, h->zig + 258, h->zig + 515};
+    p.rng_idx = rng->idx;
+    p.W = pl.W;
+    p.B = pl.B;
+    p.nsh = std::min<uint32_t>(RS_NSH, pl.W);
+    p.rsh = std::min<uint32_t>(RS_RSH, pl.W);
+    p.gacc = h->res_acc;
+    p.racc = h->res_acc + RES_GACC_WORDS;
+    p.msg = h->res_msg;
+    p.state = h->res_state;
+    {
+        // A workgroup's part of a raw dot travels as a 62-bit fixed-point integer.  |sum_i g_i eps_i| <= 2 sqrt(n sum eps^2)
+        // (Cauchy-Schwarz); the scale leaves a factor 8 of headroom for what the sweep's own updates add, and a contribution
+        // that would not fit is refused by the kernel (error 5), never wrapped
+        const double bound = 16.0 * std::sqrt((double)h->n_local * std::max(r0[1], 1e-300)) + 1.0;
+        int ex = 61 - (int)std::ceil(std::log2(bound));
+        ex = std::max(0, std::min(ex, 52));
+        p.fx_scale = std::ldexp(1.0, ex);
+        p.fx_unscale = std::ldexp(1.0, -ex);
+    }
+    p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
+    p.dbg = h->debug_timing ? 1 : 0;
+
+    HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_WORDS * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
+    HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
+    const size_t lds = std::max(rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
+    void (*kern)(ResParams) = nullptr;
+    const bool dbg = h->debug_timing;
+    switch (pl.T) {
+    case 1: kern = dbg ? k_sweep_resident<1, 1> : k_sweep_resident<1, 0>; break;
+    case 2: kern = dbg ? k_sweep_resident<2, 1> : k_sweep_resident<2, 0>; break;
+    default: kern = dbg ? k_sweep_resident<4, 1> : k_sweep_resident<4, 0>; break;
+    }
+    static bool attr_set[8] = {};
+    const int ai = (pl.T == 1 ? 0 : (pl.T == 2 ? 1 : 2)) * 2 + (dbg ? 1 : 0);
+    if (!attr_set[ai]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[ai] = true;
+    }
+    {
+        // every workgroup of the grid waits for the others: all of them must be resident at once
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, RS_BLOCK, lds));
+        if (per_cu < 1 || (uint64_t)per_cu * (uint64_t)h->num_cu < (uint64_t)pl.W + 1)
+            return fail("hgibbs_sweep: the resident grid of %u workgroups does not fit the device (%d per compute unit, %d units)", pl.W + 1, per_cu, h->num_cu);
+    }
+    if (std::getenv("HGIBBS_DEBUG"))
+        std::fprintf(stderr, "[hgibbs] resident sweep: T %d, %u streaming workgroups, window %u, LDS %zu B, fixed-point scale 2^%d\n", pl.T, pl.W, pl.B, lds, (int)std::log2(p.fx_scale));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->res_state_host, h->res_state, sizeof(ResState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const ResState& st = *h->res_state_host;
+    if (st.error)
+        return fail("hgibbs_sweep: resident engine abort code %u at cursor %u (2 = rng staging overrun, 3 = a workgroup timed out, 5 = raw dot outside the fixed-point range)", st.error, st.cursor);
+    if (st.cursor != h->M) return fail("hgibbs_sweep: resident engine stopped at cursor %u of %u", st.cursor, h->M);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    rng->idx = st.rng_idx;
+    HIP_TRY(hipMemcpy(rng->x, h->mt, MT_N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cass_host) HIP_TRY(hipMemcpy(cass_host, h->cass, (size_t)G * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nnz_updates) *nnz_updates = st.nnz;
+    hgibbs_sweep_stats& s = h->stats;
+    s = hgibbs_sweep_stats{};
+    s.launches = 1;
+    s.nnz_updates = st.nnz;
+    s.device_ms = ms;
+    s.working_launches = st.rounds;
+    s.kernel_ms_avg = st.rounds ? ms / (double)st.rounds : 0.0;
+    s.accepted_markers = st.cursor;
+    s.streamed_columns = h->M;
+    s.tiles_per_workgroup_min = s.tiles_per_workgroup_max = (uint32_t)pl.T;
+    s.engine = 2;
+    s.rounds = st.rounds;
+    s.events = st.events;
+    s.advances = st.advances;
+    s.chunks = st.chunks;
+    s.refolds = st.refolds;
+    for (int i = 0; i < 16; ++i) s.ticks[i] = st.t[i];
+    {
+        double r1[2];
+        if (reduce_eps_all(h, r1)) return 1;
+        s.eps_sum_drift = std::fabs(r1[0] - r0[0]);
+    }
+    return 0;
+}
+
+extern "C" {
 
 int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const double* sigmaG_host, const double* estPi_host,
                  const uint8_t* adaV_host, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
@@ -1215,6 +1402,17 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->desc, h->desc_host, sizeof(SweepDesc) + sizeof(SweepCounters), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream)); // staging buffers are on the host stack / pageable
 
+    // which engine runs this sweep
+    ResPlan plan{};
+    {
+        const char* why = resident_plan(h, &plan);
+        if (h->engine == 2 && why) return fail("hgibbs_sweep: the resident engine does not apply: %s", why);
+        if (h->engine == 1) plan.ok = false;
+        if (std::getenv("HGIBBS_DEBUG"))
+            std::fprintf(stderr, "[hgibbs] engine: %s%s%s\n", plan.ok ? "resident" : "batch", why ? " -- resident refused: " : "", why ? why : "");
+    }
+    if (plan.ok) return sweep_resident(h, plan, sigmaE, rng, cass_host, nnz_updates);
+
     SweepParams p{};
     p.bed = h->bed;
     p.stride = h->stride;
@@ -1225,6 +1423,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.M = M;
     p.n_minus_1 = dNm1;
     p.n_total = (double)h->n_global;
+    double eps_sum_start = 0.0;
     {
         // s2 = sum_i nm_i eps_i of a column WITHOUT missing calls is the plain sum of eps (src/BayesRRm.cpp:1788 with
         // every nm_i = 1).  A marker update adds mstd (g_i - mave) nm_i dbeta to eps_i, and mave is the mean of g over the
@@ -1235,6 +1434,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         double r[2];
         if (reduce_eps_all(h, r)) return 1;
         p.eps_sum = r[0];
+        eps_sum_start = r[0];
     }
     p.gram = h->gram ? 1 : 0;
     p.order = h->order;
@@ -1426,6 +1626,16 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     h->stats.tiles_per_workgroup_min = cnt_host->tiles_max ? cnt_host->tiles_min : 0u;
     h->stats.tiles_per_workgroup_max = cnt_host->tiles_max;
     h->stats.kernel_ms_avg = cnt_host->launches ? ms / (double)cnt_host->launches : 0.0;
+    h->stats.engine = 1;
+    h->stats.rounds = h->stats.events = h->stats.advances = h->stats.chunks = h->stats.refolds = 0;
+    for (int i = 0; i < 16; ++i) h->stats.ticks[i] = 0;
+    {
+        // s2 of the columns without missing calls was the sum of eps at sweep start for the whole sweep: what the sum is now says
+        // how far the updates' roundings have moved it (src/BayesRRm.cpp:331 re-sums eps per marker)
+        double r[2];
+        if (reduce_eps_all(h, r)) return 1;
+        h->stats.eps_sum_drift = std::fabs(r[0] - eps_sum_start);
+    }
     return 0;
 }
 

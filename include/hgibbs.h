@@ -171,6 +171,15 @@ typedef struct {
     uint64_t streamed_columns; /* batch columns whose dot product was streamed (speculative ones included, carried ones not) */
     uint32_t tiles_per_workgroup_min; /* tile groups of 4096 individuals one workgroup of the sweep kernel streamed per launch: */
     uint32_t tiles_per_workgroup_max; /* > 1 means the loop's next-tile prefetch and cross-tile accumulation ran */
+    uint32_t engine;          /* 1 = batch engine (one launch per event batch), 2 = resident engine (one launch per sweep) */
+    uint32_t reserved_;
+    double eps_sum_drift;     /* |sum(eps) at sweep end - sum(eps) at sweep start|: s2 of a column without missing calls is taken
+                               * once per sweep (src/BayesRRm.cpp:331 re-sums per marker); this is what that assumption costs */
+    /* resident engine: rounds of the walker (= working_launches), events (messages that carried an update), rounds that only
+     * advanced the window, posterior chunks evaluated, chunks that had to wait for dots streamed behind the last message */
+    uint64_t rounds, events, advances, chunks, refolds;
+    uint64_t ticks[16];       /* resident engine with option debug_timing: 100 MHz ticks, walker [0] fold [1] collect [2] evaluate
+                               * [3] scan + draw [4] message + results + prefetch; streaming workgroup 0: [8] wait [9] update [10] Gram [11] stream */
 } hgibbs_sweep_stats;
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
 /* measured streaming ceiling of this GPU: device-to-device copy of `bytes` (choose well above the 256 MB

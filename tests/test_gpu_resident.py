@@ -1,0 +1,153 @@
+"""The resident sweep engine (hydra_amd/csrc/hg_resident.hip.h: one launch per sweep, individuals sharded over the
+compute units, eps in registers, the column window in LDS, one walker workgroup) against the CPU oracle, through the C ABI.
+
+Same bar as tests/test_gpu_parity.py: marker order, mixture-component indices, cass, the generator state and the number
+of updates exact; beta, acum, the hyper-parameters and the residual within 1e-9 (the dots are summed in a different,
+fixed order -- here even as integers -- than the oracle's sequential loop).
+"""
+import numpy as np
+import pytest
+
+import orc
+from hydra_amd import capi, synth
+from test_gpu_parity import close, _same_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(M, N, seed=7, causal_frac=0.05):
+    geno = synth.make_genotypes(M, N, seed=seed, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=seed + 1, h2=0.5, causal_frac=causal_frac)
+    return synth.pack_bed_columns(geno), y
+
+
+def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None):
+    bed, y = make_case(M, N, seed=M + N, causal_frac=causal_frac)
+    ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_option("engine", 2)
+    for k, v in (opts or {}).items():
+        dev.set_option(k, v)
+    ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=seed, shuffle=1)
+    for it in range(iters):
+        ref.iterate()
+        ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        st = ch.state()
+        ss = dev.sweep_stats()
+        assert ss["engine"] == 2 and ss["launches"] == 1 and ss["accepted_markers"] == M
+        if expect_T:
+            assert ss["tiles_per_workgroup_max"] == expect_T
+        assert np.array_equal(ch.order(), ref.arr("order")), "marker order diverged at it %d" % it
+        assert np.array_equal(comp, ref.arr("components")), "component indices differ at it %d" % it
+        assert np.array_equal(st["cass"].ravel(), ref.arr("cass"))
+        assert close(beta, ref.arr("beta")), "beta beyond tolerance at it %d" % it
+        assert close(acum, ref.arr("acum"))
+        assert close(st["sigmaG"], ref.arr("sigmaG")) and close(st["estPi"].ravel(), ref.arr("estPi"))
+        assert close(st["sigmaE"], ref.sigmaE) and close(st["mu"], ref.mu)
+        rx, ridx = ref.rng_state()
+        assert st["rng_idx"] % 624 == ridx % 624 and np.array_equal(st["rng_x"], rx) or \
+            _same_stream(st["rng_x"], st["rng_idx"], rx, ridx)
+        assert close(dev.get_residual(), ref.arr("eps"), 1e-9)
+        assert ch.last_nnz() == oracle.orc_chain_last_nnz(ref.h)
+        assert ss["eps_sum_drift"] <= 1e-10 * max(1.0, abs(float(np.sum(ref.arr("eps")))))
+    return ch, ref, dev
+
+
+@pytest.mark.parametrize("N", [37, 1024, 4099, 9001])
+def test_small_shapes(oracle, N):
+    run_vs_oracle(oracle, 300, N)
+
+
+@pytest.mark.parametrize("window", [8, 32, 128, 256])
+def test_window_sizes(oracle, window):
+    # a window of 8 columns forces rounds that only advance, refills inside a walk and events at the window's edge
+    run_vs_oracle(oracle, 500, 3000, opts={"window": window})
+
+
+@pytest.mark.parametrize("cus,T", [(9, 1), (5, 2), (3, 4)])
+def test_tiles_per_workgroup(oracle, cus, T):
+    # N = 8000 -> 8 wave tiles: res_cus decides how many tiles one workgroup holds in registers
+    run_vs_oracle(oracle, 400, 8000, opts={"res_cus": cus}, expect_T=T)
+
+
+def test_many_workgroups_multishard(oracle):
+    # 20 wave tiles -> 20 streaming workgroups over 8 Gram shards and 4 raw-dot shards
+    run_vs_oracle(oracle, 400, 20011, iters=3)
+
+
+@pytest.mark.parametrize("K,mS", [(2, [0.0, 0.01]), (3, [0.0, 0.001, 0.01]), (5, [0.0, 1e-4, 1e-3, 1e-2, 1e-1]),
+                                  (8, [0.0, 1e-5, 1e-4, 5e-4, 1e-3, 5e-3, 1e-2, 1e-1])])
+def test_mixture_sizes(oracle, K, mS):
+    run_vs_oracle(oracle, 300, 2500, mS=np.array([mS]))
+
+
+def test_groups(oracle):
+    M = 400
+    groups = (np.arange(M) % 3).astype(np.int32)
+    mS = np.array([[0.0, 0.001, 0.01, 0.1], [0.0, 0.0001, 0.001, 0.01], [0.0, 0.01, 0.1, 1.0]])
+    run_vs_oracle(oracle, M, 3000, groups=groups, mS=mS)
+
+
+def test_dense_model_many_events(oracle):
+    # half of the markers causal: most rounds end on an event a few positions on; predicted and new events interleave
+    run_vs_oracle(oracle, 300, 2000, iters=4, causal_frac=0.5)
+
+
+def test_longer_chain_crosses_generator_blocks(oracle):
+    # 8 iterations of 700 markers: the walker regenerates and switches MT19937 blocks several times per sweep
+    run_vs_oracle(oracle, 700, 1500, iters=8)
+
+
+def test_engines_agree(oracle):
+    """The batch engine and the resident engine run the same chain: components identical, floating point within tolerance."""
+    M, N = 600, 6000
+    bed, y = make_case(M, N, seed=5)
+    out = []
+    for engine in (1, 2):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("engine", engine)
+        ch = capi.Chain(dev, y, seed=77, shuffle=1)
+        for _ in range(4):
+            ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        assert dev.sweep_stats()["engine"] == engine
+        out.append((beta, comp, acum, dev.get_residual(), ch.state()))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert close(out[0][0], out[1][0]) and close(out[0][2], out[1][2]) and close(out[0][3], out[1][3])
+    assert np.array_equal(out[0][4]["rng_x"], out[1][4]["rng_x"]) and out[0][4]["rng_idx"] == out[1][4]["rng_idx"]
+
+
+def test_geometry_does_not_change_the_chain(oracle):
+    """Sums over workgroups are integers (Gram terms; raw dots as fixed point): the chain is bit-identical whatever the
+    number of workgroups, tiles per workgroup or window."""
+    M, N = 500, 8000
+    bed, y = make_case(M, N, seed=9)
+    outs = []
+    for opts in ({"res_cus": 9}, {"res_cus": 5}, {"res_cus": 3, "window": 64}, {"window": 16}):
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        dev.set_option("engine", 2)
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        ch = capi.Chain(dev, y, seed=31, shuffle=1)
+        for _ in range(3):
+            ch.iterate()
+        beta, comp, acum = dev.get_beta()
+        outs.append((beta, comp, acum))
+    for o in outs[1:]:
+        assert np.array_equal(o[1], outs[0][1])
+        assert close(o[0], outs[0][0], 1e-12) and close(o[2], outs[0][2], 1e-12)
+
+
+def test_refused_where_it_does_not_apply(oracle):
+    geno = synth.make_genotypes(50, 500, seed=1, missing_rate=0.05)
+    y, _ = synth.make_phenotype(geno, seed=2)
+    dev = capi.Device(0)
+    dev.load_bed(synth.pack_bed_columns(geno), 500)
+    dev.set_option("engine", 2)
+    ch = capi.Chain(dev, y, seed=1)
+    with pytest.raises(capi.HgError, match="resident engine does not apply"):
+        ch.iterate()
