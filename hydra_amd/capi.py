@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "hgibbs_update_marker", "hgibbs_dot_marker", "hgibbs_set_covariates", "hgibbs_cov_dot", "hgibbs_cov_update",
     "hydra_chain_set_covariates", "hydra_chain_gamma", "hgibbs_set_components", "hydra_chain_restore",
     "hydra_rng_to_boost_words", "hydra_rng_from_boost_words", "hgibbs_set_model", "hgibbs_set_beta", "hgibbs_get_beta",
-    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hgibbs_stream_ceiling", "hgibbs_debug_times", "hydra_chain_create",
+    "hgibbs_beta_sqnorm", "hgibbs_sweep", "hgibbs_set_option", "hgibbs_last_sweep_stats", "hgibbs_stream_ceiling", "hgibbs_debug_times", "hgibbs_resident_trace", "hydra_chain_create",
     "hydra_chain_destroy", "hydra_chain_iterate", "hydra_chain_state", "hydra_chain_csv_line", "hydra_chain_order",
     "hydra_chain_last_nnz",
     # BayesW
@@ -138,6 +138,7 @@ def lib():
     L.hgibbs_last_sweep_stats.argtypes = [vp, C.POINTER(SweepStats)]
     L.hgibbs_stream_ceiling.argtypes = [vp, C.c_uint64, C.c_int, dp]
     L.hgibbs_debug_times.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.hgibbs_resident_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64]
     L.hydra_chain_create.argtypes = [vp, C.POINTER(ModelDesc), dp, C.POINTER(vp)]
     L.hydra_chain_destroy.argtypes = [vp]
     L.hydra_chain_iterate.argtypes = [vp]
@@ -376,6 +377,11 @@ class Device:
         check(self.L.hgibbs_sweep(self.h, _ip(order), float(sigmaE), _dp(sigmaG), _dp(estPi), _u8(adaV), C.byref(rng),
                                   _ip(cass), C.byref(nnz)))
         return cass, nnz.value
+
+    def resident_trace(self):
+        out = np.zeros((10, 4096), dtype=np.uint64)
+        check(self.L.hgibbs_resident_trace(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        return out
 
     def sweep_stats(self):
         s = SweepStats()

@@ -30,14 +30,16 @@ namespace hg {
 constexpr int RS_WAVES = 8;
 constexpr int RS_BLOCK = RS_WAVES * WAVE; // 512 threads: two waves per SIMD
 constexpr int RS_BMAX = 256;              // window capacity (columns kept in LDS as 2-bit codes)
-constexpr int RS_NSH = 8;                 // shards of the Gram accumulators (same-address atomics serialise at ~12 ns each)
-constexpr int RS_RSH = 4;                 // shards of the raw-dot accumulators (off the critical chain)
+constexpr int RS_NSH = 8;                 // shards of the Gram accumulators = waves of the walker (same-address atomics serialise at ~12 ns each)
+constexpr int RS_RSH = 8;                 // shards of the raw-dot accumulators (off the critical chain)
+constexpr int RS_GROW = 1024;             // u32 words from one Gram accumulator row to the next (4 KiB: rows on different channels)
+constexpr int RS_CROW = 1024;             // the same for the batch counters
 constexpr int RS_RB = 2 * RS_BMAX;        // raw-dot accumulators: positions mod RS_RB
 constexpr int RS_MSG = 4;                 // message slots (seq mod RS_MSG)
-constexpr int RS_PF = 8;                  // columns one wave has in flight per streaming pass
+constexpr int RS_TRACE = 4096;            // messages whose stamps the debug build keeps
 constexpr int RS_TMAX = 4;                // most wave tiles per workgroup
-constexpr unsigned long long RS_ONE = 1ull << 48; // arrival count lives in bits 48..63 of an accumulator word
-constexpr unsigned long long RS_LOW = RS_ONE - 1ull;
+constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
+constexpr uint32_t RS_LOW = RS_ONE - 1u;
 
 enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_LAST = 8 }; // message kinds; RS_LAST is a flag bit
 
@@ -52,7 +54,7 @@ struct ResState { // device -> host, written by the walker at the end of the swe
     uint32_t cursor, rng_idx, error, pad;
     unsigned long long rounds, events, advances, nnz, chunks, refolds;
     unsigned long long t[16]; // 100 MHz ticks: walker [0] fold [1] collect [2] evaluate [3] scan + draw [4] announce + outputs + prefetch;
-                              // streaming workgroup 0: [8] poll [9] update [10] Gram [11] stream
+                              // streaming workgroup 0: [8] poll [9] update [10] Gram [11] refill dots [12] barrier [13] raw atomics + drain [14] barrier + count [15] prefetch issue
 };
 
 struct ResParams {
@@ -82,12 +84,15 @@ struct ResParams {
     uint32_t W;   // streaming workgroups; the walker is workgroup W
     uint32_t B;   // window (power of two, <= RS_BMAX, B * T <= 512)
     uint32_t nsh, rsh;
-    unsigned long long* gacc; // [2][RS_NSH][RS_BMAX]
-    unsigned long long* racc; // [RS_RSH][RS_RB][2]
+    uint32_t* gacc;           // [2][RS_NSH] rows of RS_GROW words, RS_BMAX in use: count << 24 | sum of the workgroups' Gram terms
+    unsigned long long* racc; // [RS_RSH][RS_RB]: sum of the workgroups' raw dots (51-bit fixed point) of position p at p mod RS_RB
+    uint32_t* rcnt;           // [RS_RSH] words RS_CROW apart: refill batches the shard's workgroups have completed
     ResMsg* msg;              // [RS_MSG]
     ResState* state;
-    double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale) (62-bit fixed point)
+    double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale), |.| < 2^51 per workgroup
     unsigned long long timeout;  // 100 MHz ticks a spin may last
+    volatile unsigned long long* progress; // pinned host memory: [0] walker (round << 8 | stage), [1] streaming workgroup 0 (message << 8 | stage): what the host reports when its deadline passes
+    unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
 };
 
@@ -99,6 +104,10 @@ __device__ __forceinline__ u4_t rs_load16(const void* p)
     return v;
 }
 __device__ __forceinline__ void rs_store16(void* p, u4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ double rs_readlane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 {
     u4_t v;
@@ -109,11 +118,7 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
     return v;
 }
 
-__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 16 + (size_t)B * 256 * T; }
-__host__ __device__ inline size_t rs_walker_lds(uint32_t B)
-{
-    return (size_t)MT_BUF * 4 + 2 * 130 * 8 + (size_t)4 * HT_LDS * 8 + (size_t)B * (6 * 8 + 2 * 4 + 1) + 16 + (size_t)RS_BLOCK * 9 + 64 * 8 + 64 * 4 + 256 * 4 + 256;
-}
+__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 24 + (size_t)B * 256 * T; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
@@ -139,6 +144,7 @@ __device__ __forceinline__ void rs_load_col(const uint8_t* col, uint32_t voff, u
 template <int T, int DBG>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
 {
+    constexpr int RS_PF = T >= 4 ? 8 : 16; // columns one wave has in flight per streaming pass
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wg = blockIdx.x;
@@ -146,9 +152,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     double2* const tab = reinterpret_cast<double2*>(smem);                        // pair table of the event's addends (256 B)
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
     double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
-    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 16); // [B][64 * T] codes of the window columns
+    long long* const rawbuf = reinterpret_cast<long long*>(smem + 512 + (size_t)B * 16); // this round's refill: the workgroup's raw dots by position
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 24);  // [B][64 * T] codes of the window columns
     const bool timing = DBG && wg == 0 && tid == 0;
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
         if (timing) {
             const unsigned long long now = wall_clock64();
@@ -177,30 +184,45 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     uint32_t kind = RS_ADVANCE, ncons = 0;
     bool last = M == 0;
     double dbeta = 0.0;
+    // Wave v streams the positions p = v (mod 8); its k-th one, v + 8 k, lives in register set k mod RS_PF from the moment it
+    // leaves HBM until the message that admits it to the window arrives: the wave's next RS_PF columns are in registers or on
+    // their way BEFORE they are asked for, nothing is fetched twice, and the loads that refill a register set leave right
+    // after the set has been consumed -- spread over the refill's arithmetic instead of in one burst the memory queue would
+    // make the wave wait for.  Lane r keeps what belongs to set r: (mave, mstd) of its column and the marker id of its NEXT one
+    // (one vector load a round ahead: a scalar load per column would put a dependent round trip in front of every column load).
+    uint32_t cw[RS_PF][T];
+    double pm_ave = 0.0, pm_std = 0.0;
+    int32_t id_next = 0;
+    uint32_t nk = 0; // columns of this wave's residue class streamed so far: set r holds k_r = nk + ((r - nk) mod RS_PF)
+    auto pos_of = [&](uint32_t k) { return (uint32_t)wave + 8u * k; };
+    {
+        const uint32_t mp = pos_of((uint32_t)lane);
+        int32_t id0 = 0;
+        if (lane < RS_PF && mp < M) {
+            id0 = p.order[mp];
+            pm_ave = p.s_mave[mp];
+            pm_std = p.s_mstd[mp];
+        }
+        const uint32_t mp2 = pos_of((uint32_t)lane + RS_PF);
+        if (lane < RS_PF && mp2 < M) id_next = p.order[mp2];
+#pragma unroll
+        for (int r = 0; r < RS_PF; ++r) {
+            if (pos_of((uint32_t)r) < M) {
+                rs_load_col<T>(p.bed + (size_t)__builtin_amdgcn_readlane(id0, r) * p.stride, voff, cw[r]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) cw[r][t] = 0u;
+            }
+        }
+    }
     for (;;) {
         const bool upd = kind == RS_EVENT;
+        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
         const uint32_t Cn = C + ncons;
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         const uint32_t nnew = Sn - Sx;
-        const uint32_t first = Sx + (uint32_t)wave;
-        const uint32_t count_w = nnew > (uint32_t)wave ? (nnew - (uint32_t)wave + 7u) / 8u : 0u; // positions first + 8 k
-
-        uint32_t cw[RS_PF][T];
-        auto issue = [&](uint32_t k0) {
-#pragma unroll
-            for (int k = 0; k < RS_PF; ++k) {
-                if (k0 + (uint32_t)k < count_w) {
-                    const uint32_t pos = __builtin_amdgcn_readfirstlane(first + 8u * (k0 + (uint32_t)k));
-                    const int32_t mk = p.order[pos];
-                    rs_load_col<T>(p.bed + (size_t)mk * p.stride, voff, cw[k]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) cw[k][t] = 0u;
-                }
-            }
-        };
-        issue(0u); // the refill's first columns are on their way from HBM while the event is applied
+        uint32_t count_w = (Sn > (uint32_t)wave ? (Sn - (uint32_t)wave + 7u) / 8u : 0u) - nk; // this wave's positions in [Sx, Sn)
 
         if (upd) {
             // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave ----
@@ -219,11 +241,13 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
 #pragma unroll
             for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
             lap(1);
+            if (timing) p.trace[5 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
 
             // ---- integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind q (their dots were taken before this
             // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
             const uint32_t V = Sx - (q + 1u);
             const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
+            if (V) {
             GramPivot gp[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) gp[t] = gram_pivot(xq[t]);
@@ -231,14 +255,24 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0u;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                if ((uint32_t)c < Vw && i0 + (uint32_t)c < V) { // wave-uniform
-                    const uint32_t slot = (q + 1u + i0 + (uint32_t)c) & bmask;
-                    const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-                    uint32_t g = 0u;
+            for (int cb = 0; cb < 32; cb += 8) {
+                if ((uint32_t)cb < Vw) { // wave-uniform; the eight columns of a group are read together (past the end: column V - 1 again, unused)
+                    uint32_t wv[8][T];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) g += gram16x(gram_xform(rp[t]), gp[t]);
-                    acc[c >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t i = i0 + (uint32_t)(cb + c);
+                        const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
+                        const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) wv[c][t] = rp[t];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        uint32_t g = 0u;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) g += gram16x(gram_xform(wv[c][t]), gp[t]);
+                        acc[(cb + c) >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
+                    }
                 }
             }
             uint32_t mine = 0u;
@@ -249,20 +283,27 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     mine = (lane == 2 * r) ? (tot & 0xffffu) : ((lane == 2 * r + 1) ? (tot >> 16) : mine);
                 }
             }
-            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
-                unsigned long long* a = p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_BMAX + i0 + (uint32_t)lane;
-                __hip_atomic_fetch_add(a, RS_ONE | (unsigned long long)mine, HG_RLX_AGENT);
+            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words: count in the top byte
+                __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
             }
             ++nev;
             lap(2);
+            if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
-        for (uint32_t k0 = 0; k0 < count_w; k0 += RS_PF) {
-            if (k0) issue(k0);
+        while (count_w) {
+            const uint32_t m = count_w < (uint32_t)RS_PF ? count_w : (uint32_t)RS_PF; // register sets in use this pass: k in [nk, nk + m)
 #pragma unroll
             for (int g = 0; g < RS_PF / 4; ++g) {
-                if (k0 + 4u * g < count_w) { // wave-uniform
+                uint32_t kr[4];
+                bool act[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    kr[c] = nk + (((uint32_t)(4 * g + c) - nk) & (uint32_t)(RS_PF - 1));
+                    act[c] = kr[c] - nk < m;
+                }
+                if (act[0] || act[1] || act[2] || act[3]) { // wave-uniform
                     double a[4] = {0.0, 0.0, 0.0, 0.0};
                     uint32_t gw[4][T];
 #pragma unroll
@@ -274,39 +315,74 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         fma_slots4(gw[0][t], gw[1][t], gw[2][t], gw[3][t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT>{});
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const uint32_t kk = k0 + 4u * g + (uint32_t)c;
-                        if (kk < count_w) { // wave-uniform
-                            const uint32_t pos = __builtin_amdgcn_readfirstlane(first + 8u * kk);
+                        if (act[c]) { // wave-uniform
+                            const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr[c]));
                             const uint32_t slot = pos & bmask;
                             uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
 #pragma unroll
                             for (int t = 0; t < T; ++t) rp[t] = gw[c][t];
-                            if (lane == 0) meta[slot] = make_double2(p.s_mave[pos], p.s_mstd[pos]);
+                            {
+                                const double ma = rs_readlane(pm_ave, 4 * g + c), ms = rs_readlane(pm_std, 4 * g + c);
+                                if (lane == 0) meta[slot] = make_double2(ma, ms);
+                            }
+                            // the workgroup's part of s1 travels as a 51-bit fixed-point integer, taken from "x + 1.5 2^52" (round to
+                            // nearest, exact for |x| < 2^51): sums over workgroups are then exact and order-independent
                             const double s1 = wave_sum(a[c]);
-                            const double sc = s1 * p.fx_scale;
-                            if (!(fabs(sc) < 4.0e18)) { // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
+                            const double xs = s1 * p.fx_scale;
+                            if (!(fabs(xs) < 2.2e15)) { // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
                                 if (lane == 0) atomicMax(&p.state->error, 5u);
                             }
-                            const long long v = __double2ll_rn(sc);
-                            const unsigned long long lo = (unsigned long long)(uint32_t)v;
-                            const unsigned long long hi = (unsigned long long)(uint32_t)((v >> 32) + 0x80000000ll);
-                            if (lane < 2) {
-                                unsigned long long* a2 = p.racc + (((size_t)(wg % p.rsh) * RS_RB + (pos % RS_RB)) << 1) + (uint32_t)lane;
-                                __hip_atomic_fetch_add(a2, RS_ONE | (lane ? hi : lo), HG_RLX_AGENT);
+                            const double MAGIC = 6755399441055744.0;
+                            if (lane == 0) rawbuf[pos - Sx] = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
+                            // the set's next column leaves HBM now
+                            const uint32_t pn = __builtin_amdgcn_readfirstlane(pos_of(kr[c] + (uint32_t)RS_PF));
+                            if (pn < M) {
+                                rs_load_col<T>(p.bed + (size_t)__builtin_amdgcn_readlane(id_next, 4 * g + c) * p.stride, voff, cw[4 * g + c]);
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < T; ++t) cw[4 * g + c][t] = 0u;
                             }
                         }
                     }
                 }
             }
+            // lanes of the sets that were refilled: their column's (mave, mstd) and the id of the one after it
+            {
+                const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));
+                if (lane < RS_PF && kl - nk < m) {
+                    const uint32_t mp = pos_of(kl + (uint32_t)RS_PF), mp2 = pos_of(kl + 2u * (uint32_t)RS_PF);
+                    if (mp < M) {
+                        pm_ave = p.s_mave[mp];
+                        pm_std = p.s_mstd[mp];
+                    }
+                    id_next = mp2 < M ? p.order[mp2] : 0;
+                }
+            }
+            nk += m;
+            count_w -= m;
         }
         lap(3);
-        __syncthreads(); // the window's new columns are in LDS for every wave
+        __syncthreads(); // the window's new columns and this round's raw dots are in LDS for every wave
+        lap(4);
+        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
+        // the refill's raw dots go out as contiguous 8-byte atomic adds (one 64-byte request per eight positions), then -- once
+        // they have been performed -- one add to the shard's batch counter tells the walker that this workgroup's part is in
+        for (uint32_t t = (uint32_t)tid; t < nnew; t += RS_BLOCK)
+            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)rawbuf[t], HG_RLX_AGENT);
+        wait_vmcnt<0>();
+        lap(5);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
+        lap(6);
+        if (timing) p.trace[7 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         C = Cn;
         Sx = Sn;
         if (last) break;
+        lap(7);
 
         // ---- wait for the walker's next message (one lane polls; everybody else sleeps at the barrier) ----
         ++seq;
+        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 3u;
         if (tid == 0) {
             const ResMsg* m = p.msg + (seq % RS_MSG);
             const unsigned long long t0 = wall_clock64();
@@ -333,6 +409,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         last = (kf & RS_LAST) != 0u;
         ncons = (uint32_t)tag & 0x0fffffffu;
         lap(0);
+        if (timing) p.trace[4 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         if (kind == RS_ABORT) break;
     }
 
@@ -346,7 +423,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         }
     }
     if (timing)
-        for (int i = 0; i < 4; ++i) p.state->t[8 + i] = tacc[i];
+        for (int i = 0; i < 8; ++i) p.state->t[8 + i] = tacc[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -355,19 +432,24 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
 struct WalkShared {
     uint32_t* mt;
     double *zig_nx, *zig_ny, *htab;
-    double *mave, *mstd, *bold, *dp, *thr0, *num; // window slots
+    double *mave, *mstd, *bold, *dp, *dpr, *thr0, *num; // window slots (dp: Gram corrections so far, dpr: the dot as streamed)
     int32_t *marker, *grp;
+    uint32_t* batch; // refill batch (= message number) that streamed the slot's column
+    uint32_t* gpart; // [RS_NSH][RS_BMAX] the shards' Gram sums of the event being collected
+    unsigned long long* rprev; // [RS_RB] sum over the shards of the raw-dot words as last seen (they only ever grow)
     uint8_t* ada;
+    uint8_t* fdone; // the slot's raw dot has arrived
+    unsigned char* end;
     double* ebuf;   // [RS_BLOCK] exp(logL_l - logL_0) of the chunk under evaluation
     uint8_t* bigf;  // [RS_BLOCK]
     double* fd;     // 64 doubles of scratch (event: dbeta, bnew, prob, ...)
     uint32_t* fl;   // 64 words of flags
     int32_t* lcass; // [256]
 };
-enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_NADA = 6 };
+enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7 };
 enum { WD_DBETA = 0, WD_BNEW = 1, WD_PROB = 2 };
 
-__device__ __forceinline__ WalkShared walk_carve(unsigned char* q, uint32_t B)
+__host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
 {
     WalkShared s;
     s.mt = reinterpret_cast<uint32_t*>(q); q += MT_BUF * 4;
@@ -378,18 +460,26 @@ __device__ __forceinline__ WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.mstd = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.bold = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.dp = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.dpr = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.thr0 = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.num = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.ebuf = reinterpret_cast<double*>(q); q += (size_t)RS_BLOCK * 8;
+    s.rprev = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
     s.marker = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
     s.grp = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
+    s.batch = reinterpret_cast<uint32_t*>(q); q += (size_t)B * 4;
+    s.gpart = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_NSH * RS_BMAX * 4;
     s.fl = reinterpret_cast<uint32_t*>(q); q += 64 * 4;
     s.lcass = reinterpret_cast<int32_t*>(q); q += 256 * 4;
     s.bigf = q; q += RS_BLOCK;
-    s.ada = q;
+    s.ada = q; q += B;
+    s.fdone = q; q += B;
+    s.end = q;
     return s;
 }
+// bytes of LDS the walker needs: the end of its own carve-up (so that the two cannot disagree)
+__host__ __device__ inline size_t rs_walker_lds(uint32_t B) { return (size_t)(walk_carve(nullptr, B).end - (unsigned char*)nullptr) + 64; }
 
 template <int DBG>
 __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* smem)
@@ -418,6 +508,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     if (lds_tab)
         for (int i = tid; i < 4 * p.GK; i += RS_BLOCK) sh.htab[(i / p.GK) * HT_LDS + (i % p.GK)] = p.denom[i];
     for (int i = tid; i < 256; i += RS_BLOCK) sh.lcass[i] = 0;
+    for (int i = tid; i < RS_RB; i += RS_BLOCK) sh.rprev[i] = 0ull;
     if (tid < 64) sh.fl[tid] = 0u;
     auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
         if (lds_tab) return sh.htab[which * HT_LDS + t];
@@ -425,7 +516,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     };
 
     // window slots of the positions [lo, hi): per-marker metadata, dot accumulator reset
-    auto prefetch = [&](uint32_t lo, uint32_t hi) {
+    auto prefetch = [&](uint32_t lo, uint32_t hi, uint32_t batch) {
         for (uint32_t j = lo + (uint32_t)tid; j < hi; j += RS_BLOCK) {
             const uint32_t slot = j & bmask;
             const int ga = p.s_ga[j];
@@ -436,93 +527,99 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.mave[slot] = p.s_mave[j];
             sh.mstd[slot] = p.s_mstd[j];
             sh.dp[slot] = 0.0;
+            sh.fdone[slot] = 0;
+            sh.batch[slot] = batch;
         }
     };
 
-    uint32_t cntG[RS_NSH], cntR[RS_RSH];
-#pragma unroll
-    for (int s = 0; s < RS_NSH; ++s) cntG[s] = (uint32_t)s < p.nsh ? p.W / p.nsh + ((uint32_t)s < p.W % p.nsh ? 1u : 0u) : 0u;
-#pragma unroll
-    for (int s = 0; s < RS_RSH; ++s) cntR[s] = (uint32_t)s < p.rsh ? p.W / p.rsh + ((uint32_t)s < p.W % p.rsh ? 1u : 0u) : 0u;
+    // arrivals per shard: shards below W mod n hold one workgroup more ([0]) than the others ([1])
+    const uint32_t cntG[2] = {p.W / p.nsh + (p.W % p.nsh ? 1u : 0u), p.W / p.nsh};
+    const uint32_t cntR[2] = {p.W / p.rsh + (p.W % p.rsh ? 1u : 0u), p.W / p.rsh};
 
-    uint32_t C = 0, Sx = (B < M) ? B : M, SxPrev = Sx, F = 0, rpos = p.rng_idx, seq = 0, nev = 0;
+    uint32_t C = 0, Sx = (B < M) ? B : M, F = 0, rpos = p.rng_idx, seq = 0, nev = 0;
+    u4_t gprev0 = rs_u4(0u, 0u, 0u, 0u), gprev1 = rs_u4(0u, 0u, 0u, 0u); // this lane's four words of its shard's row as last seen, per parity
     bool has_next = false, aborted = false;
     bool pendG = false;
     uint32_t gq = 0, gV = 0;          // the event whose Gram terms are still to be collected: position, window columns behind it
     double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0;
     unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0;
-    prefetch(0u, Sx);
+    prefetch(0u, Sx, 0u);
     __syncthreads();
 
-    // raw dots of the positions [F, hi): sum of the workgroups' fixed-point contributions -> s1 -> x_j'eps
-    auto fold = [&](uint32_t hi) {
-        for (uint32_t j = F + (uint32_t)tid; j < hi; j += RS_BLOCK) {
-            const uint32_t slot = j & bmask;
-            unsigned long long* base = p.racc + ((size_t)(j % RS_RB) << 1);
-            unsigned long long w[RS_RSH][2];
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                bool ok = true;
+    // Refill batches all workgroups have completed (their raw dots are summed in racc): wave 0 reads the shards' counters.
+    auto refresh_batches = [&]() {
+        if (tid < WAVE) {
+            uint32_t b = 0xffffffffu;
+            if ((uint32_t)lane < p.rsh) b = __hip_atomic_load(p.rcnt + (size_t)lane * RS_CROW, HG_RLX_AGENT) / cntR[0 + ((uint32_t)lane < p.W % p.rsh ? 0 : 1)];
 #pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) {
-                    if ((uint32_t)s < p.rsh) {
-                        w[s][0] = __hip_atomic_load(base + (size_t)s * RS_RB * 2, HG_RLX_AGENT);
-                        w[s][1] = __hip_atomic_load(base + (size_t)s * RS_RB * 2 + 1, HG_RLX_AGENT);
-                    } else {
-                        w[s][0] = w[s][1] = 0ull;
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) ok = ok && (uint32_t)(w[s][0] >> 48) == cntR[s] && (uint32_t)(w[s][1] >> 48) == cntR[s];
-                if (ok) break;
-                if (wall_clock64() - t0 > p.timeout) {
-                    sh.fl[WF_ABORT] = 1u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+                b = o < b ? o : b;
             }
-            unsigned long long slo = 0ull, shi = 0ull;
-#pragma unroll
-            for (int s = 0; s < RS_RSH; ++s) {
-                slo += w[s][0] & RS_LOW;
-                shi += w[s][1] & RS_LOW;
-                if ((uint32_t)s < p.rsh) { // free for position j + RS_RB (streamed only after a later message: the stores are drained before every message)
-                    __hip_atomic_store(base + (size_t)s * RS_RB * 2, 0ull, HG_RLX_AGENT);
-                    __hip_atomic_store(base + (size_t)s * RS_RB * 2 + 1, 0ull, HG_RLX_AGENT);
-                }
-            }
-            const long long hi_sum = (long long)shi - (long long)p.W * 0x80000000ll;
-            const long long tot = (long long)((unsigned long long)hi_sum << 32) + (long long)slo;
-            const double s1 = (double)tot * p.fx_unscale;
-            sh.dp[slot] += sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
+            if (lane == 0) sh.fl[WF_RDONE] = b;
         }
-        if (hi > F) F = hi;
+    };
+    // The raw dot of position j, once its batch is complete: sum of the shards' words (wrapping 64-bit sums of the workgroups'
+    // fixed-point parts) minus what they held before this batch (position j - RS_RB used them last; no store ever touches
+    // them), s1 -> x_j'eps (:1785-1790,1809 with s2 = sum of eps).  Else j is a candidate for the first position still missing.
+    auto try_raw = [&](uint32_t j, uint32_t done) {
+        const uint32_t slot = j & bmask;
+        if (sh.fdone[slot]) return;
+        if (sh.batch[slot] >= done) {
+            atomicMin(&sh.fl[WF_FMIN], j);
+            return;
+        }
+        unsigned long long* base = p.racc + (j % RS_RB);
+        unsigned long long w[RS_RSH];
+#pragma unroll
+        for (int s = 0; s < RS_RSH; ++s) w[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
+        unsigned long long now = 0ull;
+#pragma unroll
+        for (int s = 0; s < RS_RSH; ++s) now += w[s];
+        const unsigned long long tot = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic)
+        sh.rprev[j % RS_RB] = now;
+        const double s1 = (double)(long long)tot * p.fx_unscale;
+        sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
+        sh.fdone[slot] = 1;
+    };
+    // one pass over the positions [F, Sx) that have no dot yet; afterwards F = the first one still missing
+    auto fold_pass = [&]() {
+        refresh_batches();
+        if (tid == 0) sh.fl[WF_FMIN] = Sx;
+        __syncthreads();
+        const uint32_t done = sh.fl[WF_RDONE];
+        for (uint32_t j = F + (uint32_t)tid; j < Sx; j += RS_BLOCK) try_raw(j, done);
+        __syncthreads();
+        F = sh.fl[WF_FMIN];
     };
 
     for (;;) {
         if (C >= M) break;
         ++n_rounds;
+        if (tid == 0) p.progress[0] = (n_rounds << 8) | 1u;
         // generator: the next block exists before a round can run into it
         if (!has_next && rpos + B + 96u > (uint32_t)MT_N) {
             mt_next_block(sh.mt, tid);
             has_next = true;
         }
-        // 1. dots of everything streamed before the last message
-        fold(SxPrev);
-        __syncthreads(); // (a slot may get its dot from one thread and its correction from another)
-        lap(0);
-        // 2. Gram corrections of the last event for the window columns behind it
-        if (pendG) {
-            if ((uint32_t)tid < gV) {
-                unsigned long long* base = p.gacc + (size_t)((nev - 1u) & 1u) * RS_NSH * RS_BMAX + (uint32_t)tid;
-                unsigned long long w[RS_NSH];
+        // 1. Gram terms of the window columns behind the last event (the streaming workgroups' first job after a message): wave s
+        // polls shard s's row, 16 bytes per lane; every word in use must carry the shard's full arrival count
+        if (pendG && gV) {
+            const int ws = tid >> 6;
+            const uint32_t par = (nev - 1u) & 1u;
+            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < gV) {
+                const uint32_t* row = p.gacc + ((size_t)par * RS_NSH + (uint32_t)ws) * RS_GROW + 4u * (uint32_t)lane;
+                const uint32_t want = cntG[0 + ((uint32_t)ws < p.W % p.nsh ? 0 : 1)];
                 const unsigned long long t0 = wall_clock64();
+                // the words only ever grow (no store ever touches them: adds are performed at the memory side, and a store could
+                // overtake or be overtaken by one): what this event added is the difference to what the lane saw last time
+                u4_t v, d;
                 for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int s = 0; s < RS_NSH; ++s) w[s] = (uint32_t)s < p.nsh ? __hip_atomic_load(base + (size_t)s * RS_BMAX, HG_RLX_AGENT) : 0ull;
-#pragma unroll
-                    for (int s = 0; s < RS_NSH; ++s) ok = ok && (uint32_t)(w[s] >> 48) == cntG[s];
+                    v = rs_load16(row);
+                    d = par ? (v - gprev1) : (v - gprev0);
+                    const uint32_t i = 4u * (uint32_t)lane;
+                    const bool ok = (d.x >> 24) == want && (i + 1u >= gV || (d.y >> 24) == want) && (i + 2u >= gV || (d.z >> 24) == want) &&
+                                    (i + 3u >= gV || (d.w >> 24) == want);
                     if (ok) break;
                     if (wall_clock64() - t0 > p.timeout) {
                         sh.fl[WF_ABORT] = 1u;
@@ -530,38 +627,56 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                unsigned long long A = 0ull;
-#pragma unroll
-                for (int s = 0; s < RS_NSH; ++s) {
-                    A += w[s] & RS_LOW;
-                    if ((uint32_t)s < p.nsh) __hip_atomic_store(base + (size_t)s * RS_BMAX, 0ull, HG_RLX_AGENT);
-                }
+                // (a word beyond gV got no add this time: its difference is zero and its previous value stays what it is)
+                if (par) gprev1 = v;
+                else gprev0 = v;
+                uint32_t* gp = sh.gpart + (uint32_t)ws * RS_BMAX + 4u * (uint32_t)lane;
+                gp[0] = d.x & RS_LOW;
+                gp[1] = d.y & RS_LOW;
+                gp[2] = d.z & RS_LOW;
+                gp[3] = d.w & RS_LOW;
+            }
+            __syncthreads();
+            if ((uint32_t)tid < gV) {
+                uint32_t A = 0u;
+                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart[sidx * RS_BMAX + (uint32_t)tid];
                 const uint32_t slot = (gq + 1u + (uint32_t)tid) & bmask;
                 const double mj = sh.mave[slot], sj = sh.mstd[slot];
                 const double xx = sj * g_mstd * ((double)A - p.n_total * (mj * g_mave));
                 sh.dp[slot] += g_db * xx;
             }
-            pendG = false;
         }
+        pendG = false;
         __syncthreads();
         lap(1);
+        if (DBG && tid == 0) p.trace[1 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         if (sh.fl[WF_ABORT]) {
             aborted = true;
             break;
         }
 
         // 3. the walk: posterior of a chunk of markers in parallel, then wave 0 consumes the stream in marker order
+        if (tid == 0) p.progress[0] = (n_rounds << 8) | 2u;
         uint32_t base = C;
         bool found = false;
         while (!found && base < Sx) {
-            const uint32_t nevl = (Sx - base < EV) ? Sx - base : EV;
-            if (base + nevl > F) { // reaches into the columns streamed behind the last message: their dots are needed now
+            if (base >= F) { // the walk needs dots that are still on their way: wait for them
                 ++n_refold;
-                fold(base + nevl);
+                if (tid == 0) p.progress[0] = (n_rounds << 8) | 3u;
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    __syncthreads();
+                    if (tid == 0 && wall_clock64() - t0 > p.timeout) sh.fl[WF_ABORT] = 1u; // (one thread decides: the exit must be uniform)
+                    fold_pass();
+                    if (F > base || sh.fl[WF_ABORT]) break;
+                }
                 __syncthreads();
                 if (sh.fl[WF_ABORT]) break;
+                lap(0);
             }
+            const uint32_t nevl = (F - base < EV) ? F - base : EV;
             ++n_chunks;
+            if (tid == 0) p.progress[0] = (n_rounds << 8) | 4u;
             {
                 const uint32_t jj = (uint32_t)tid / (uint32_t)K;
                 const int l = (int)((uint32_t)tid % (uint32_t)K);
@@ -569,7 +684,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                     const uint32_t slot = (base + jj) & bmask;
                     if (sh.ada[slot]) {
                         const int g0 = sh.grp[slot] * K;
-                        const double num = sh.dp[slot] + sh.bold[slot] * p.n_minus_1;
+                        const double num = (sh.dpr[slot] + sh.dp[slot]) + sh.bold[slot] * p.n_minus_1;
                         const double L0 = tabv(1, g0);
                         double L = L0;
                         if (l > 0) {
@@ -710,6 +825,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         }
 
         // 4. the message
+        if (tid == 0) p.progress[0] = (n_rounds << 8) | 5u;
         const uint32_t qpos = found ? sh.fl[WF_Q] : 0u;
         const uint32_t ncons = found ? qpos - C + 1u : Sx - C;
         const double dbeta = found ? sh.fd[WD_DBETA] : 0.0, bnew = found ? sh.fd[WD_BNEW] : 0.0;
@@ -717,9 +833,13 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         const bool is_event = found && dbeta != 0.0;
         const uint32_t Cn = C + ncons;
         const bool lastmsg = Cn >= M;
-        wait_vmcnt<0>(); // this wave's zeroing stores have landed ...
-        __syncthreads(); // ... and everybody else's
+        __syncthreads();
         ++seq;
+        if (DBG && tid == 0) {
+            p.trace[2 * RS_TRACE + (seq - 1u) % RS_TRACE] = wall_clock64();
+            p.trace[3 * RS_TRACE + (seq - 1u) % RS_TRACE] = ncons;
+            p.trace[0 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+        }
         if (tid == 0) {
             const uint32_t kf = (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE) | (lastmsg ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
@@ -745,6 +865,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             const uint32_t slot = j & bmask;
             const int marker = sh.marker[slot];
             const bool isq = found && j == qpos;
+            if (DBG) { // the dot as streamed and its Gram corrections, by sweep position (tools/dbg_res.py)
+                p.trace[8 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dpr[slot]);
+                p.trace[9 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dp[slot]);
+            }
             if (sh.ada[slot]) {
                 const int kk = isq ? kq : 0;
                 p.beta[marker] = isq ? bnew : 0.0;
@@ -761,16 +885,17 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         }
         __syncthreads();
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
-        prefetch(Sx, Sn);
+        prefetch(Sx, Sn, seq);
         if (rpos >= (uint32_t)MT_N) { // the stream crossed into the next block: it becomes the current one
             for (int i = tid; i < MT_N; i += RS_BLOCK) sh.mt[i] = sh.mt[MT_N + i];
             rpos -= (uint32_t)MT_N;
             has_next = false;
         }
         __syncthreads();
-        SxPrev = Sx;
         Sx = Sn;
         C = Cn;
+        if (tid == 0) p.progress[0] = (n_rounds << 8) | 6u;
+        fold_pass(); // dots of the refills that have arrived meanwhile (off the chain: the streaming workgroups are busy with the message)
         lap(4);
     }
 

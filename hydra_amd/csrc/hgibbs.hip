@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -146,11 +148,14 @@ struct hgibbs_ctx {
     int engine = 0;           // option engine: 0 auto (resident where it applies), 1 batch engine (k_sweep_batch), 2 resident (refused where it does not apply)
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
-    unsigned long long* res_acc = nullptr; // Gram + raw-dot accumulators
+    unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
     ResMsg* res_msg = nullptr;
     ResState* res_state = nullptr;
     ResState* res_state_host = nullptr; // pinned
+    unsigned long long* res_progress = nullptr; // pinned, written by the kernel while it runs
+    unsigned long long* res_trace = nullptr; // [8][RS_TRACE], debug_timing
     double res_timeout_s = 2.0;
+    double res_deadline_s = 0.0; // option res_deadline_ms: the host's deadline for a resident sweep (0 = derived)
 
     hgibbs_sweep_stats stats{};
 };
@@ -164,8 +169,8 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
     return 0;
 }
 
-static constexpr size_t RES_GACC_WORDS = (size_t)2 * RS_NSH * RS_BMAX, RES_RACC_WORDS = (size_t)RS_RSH * RS_RB * 2;
-static constexpr size_t RES_ACC_WORDS = RES_GACC_WORDS + RES_RACC_WORDS;
+static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4;
+static constexpr size_t RES_ACC_BYTES = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES;
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
 static constexpr size_t MBOX_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long);
 
@@ -563,10 +568,13 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMalloc(&h->dbg, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 4096 * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->res_acc, RES_ACC_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->res_acc, RES_ACC_BYTES));
     HIP_TRY(hipMalloc(&h->res_msg, RS_MSG * sizeof(ResMsg)));
     HIP_TRY(hipMalloc(&h->res_state, sizeof(ResState)));
     HIP_TRY(hipHostMalloc(&h->res_state_host, sizeof(ResState)));
+    HIP_TRY(hipHostMalloc(&h->res_progress, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->res_trace, (size_t)10 * RS_TRACE * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->res_trace, 0, (size_t)10 * RS_TRACE * sizeof(unsigned long long)));
     *out = h;
     return 0;
 }
@@ -582,12 +590,13 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket, h->res_acc, h->res_msg, h->res_state};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket, h->res_acc, h->res_msg, h->res_state, h->res_trace};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
     if (h->scratch_host) (void)hipHostFree(h->scratch_host);
     if (h->res_state_host) (void)hipHostFree(h->res_state_host);
+    if (h->res_progress) (void)hipHostFree(h->res_progress);
     if (h->beta_host) (void)hipHostFree(h->beta_host);
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
@@ -1123,6 +1132,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "res_cus")) {
         if (value < 0 || value > 4096) return fail("res_cus must be in [0,4096]");
         h->res_cus = (uint32_t)value;
+    } else if (!std::strcmp(name, "res_deadline_ms")) {
+        h->res_deadline_s = (double)value * 1e-3;
     } else if (!std::strcmp(name, "res_timeout_ms")) {
         if (value < 1) return fail("res_timeout_ms must be positive");
         h->res_timeout_s = (double)value * 1e-3;
@@ -1151,6 +1162,15 @@ int hgibbs_debug_times(hgibbs_t h, uint64_t* out8)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpy(out8, h->dbg, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(h->dbg, 0, 48 * sizeof(unsigned long long)));
+    return 0;
+}
+
+int hgibbs_resident_trace(hgibbs_t h, uint64_t* out, uint64_t words)
+{
+    if (!h || !out) return fail("null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint64_t n = std::min<uint64_t>(words, (uint64_t)10 * RS_TRACE);
+    HIP_TRY(hipMemcpy(out, h->res_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1253,24 +1273,30 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.B = pl.B;
     p.nsh = std::min<uint32_t>(RS_NSH, pl.W);
     p.rsh = std::min<uint32_t>(RS_RSH, pl.W);
-    p.gacc = h->res_acc;
-    p.racc = h->res_acc + RES_GACC_WORDS;
+    p.gacc = reinterpret_cast<uint32_t*>(h->res_acc);
+    p.racc = reinterpret_cast<unsigned long long*>(h->res_acc + RES_GACC_BYTES);
+    p.rcnt = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES);
     p.msg = h->res_msg;
     p.state = h->res_state;
     {
-        // A workgroup's part of a raw dot travels as a 62-bit fixed-point integer.  |sum_i g_i eps_i| <= 2 sqrt(n sum eps^2)
-        // (Cauchy-Schwarz); the scale leaves a factor 8 of headroom for what the sweep's own updates add, and a contribution
-        // that would not fit is refused by the kernel (error 5), never wrapped
-        const double bound = 16.0 * std::sqrt((double)h->n_local * std::max(r0[1], 1e-300)) + 1.0;
-        int ex = 61 - (int)std::ceil(std::log2(bound));
-        ex = std::max(0, std::min(ex, 52));
+        // A workgroup's part of a raw dot travels as a fixed-point integer of at most 51 bits (units of 1 / fx_scale), the sum over the
+        // workgroups as a wrapping 64-bit integer.  |sum_i g_i eps_i| <= 2 sqrt(n sum eps^2) over the workgroup's n = 1024 T
+        // individuals (Cauchy-Schwarz, with the sum of squares of ALL individuals); the scale leaves a factor 8 for what the
+        // sweep's own updates add, and a contribution that would not fit is refused by the kernel (error 5), never wrapped.
+        // Resolution: 1 / fx_scale (~1e-10 at config 4 against dots of order 10^2..10^3)
+        const double bound = 16.0 * std::sqrt(1024.0 * pl.T * std::max(r0[1], 1e-300)) + 1.0;
+        int ex = 50 - (int)std::ceil(std::log2(bound));
+        ex = std::max(-40, std::min(ex, 60));
         p.fx_scale = std::ldexp(1.0, ex);
         p.fx_unscale = std::ldexp(1.0, -ex);
     }
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.dbg = h->debug_timing ? 1 : 0;
+    p.trace = h->res_trace;
+    p.progress = h->res_progress;
+    for (int i = 0; i < 16; ++i) h->res_progress[i] = 0;
 
-    HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_WORDS * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
     const size_t lds = std::max(rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
@@ -1301,7 +1327,27 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipMemcpyAsync(h->res_state_host, h->res_state, sizeof(ResState), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+        // the kernel bounds every wait of its own; the host's deadline is the last line of defence (a kernel that does not come
+        // back is reported with where its walker and its first streaming workgroup stand, not waited for)
+        const auto t_start = std::chrono::steady_clock::now();
+        const double limit_s = h->res_deadline_s > 0.0 ? h->res_deadline_s : 30.0 + 20.0 * h->res_timeout_s + 1e-6 * (double)h->M;
+        for (;;) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail("hgibbs_sweep: resident engine: %s", hipGetErrorString(q));
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if (el > limit_s)
+            {
+                if (std::getenv("HGIBBS_DEBUG"))
+                    for (int i = 2; i < 10; ++i) std::fprintf(stderr, "[hgibbs] progress[%d] = %llu\n", i, (unsigned long long)h->res_progress[i]);
+                return fail("hgibbs_sweep: the resident kernel has not come back after %.0f s: walker at round %llu stage %llu, streaming workgroup 0 at message %llu stage %llu", el,
+                            (unsigned long long)(h->res_progress[0] >> 8), (unsigned long long)(h->res_progress[0] & 255u), (unsigned long long)(h->res_progress[1] >> 8),
+                            (unsigned long long)(h->res_progress[1] & 255u));
+            }
+            if (el > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.5 ? 2000 : 50));
+        }
+    }
     const ResState& st = *h->res_state_host;
     if (st.error)
         return fail("hgibbs_sweep: resident engine abort code %u at cursor %u (2 = rng staging overrun, 3 = a workgroup timed out, 5 = raw dot outside the fixed-point range)", st.error, st.cursor);

@@ -188,6 +188,11 @@ int hgibbs_stream_ceiling(hgibbs_t h, uint64_t bytes, int reps, double* gbps);
 /* diagnostic: the 48 accumulated stage-timestamp words (100 MHz ticks) of the sweep kernel's build with option
  * debug_timing = 1 since the last call (which clears them): bench.py's launch anatomy, tools/dbg_times.py */
 int hgibbs_debug_times(hgibbs_t h, uint64_t* out48);
+/* diagnostic: wall-clock stamps (100 MHz) of the resident engine's last 4096 messages, taken by the build with option
+ * debug_timing = 1: 8 rows of 4096 words indexed by message number mod 4096 -- walker: [0] message stored, [1] its Gram
+ * terms collected, [2] next message decided, [3] positions it consumed; streaming workgroup 0: [4] message seen, [5] eps
+ * updated, [6] Gram terms sent, [7] refill streamed (tools/res_anatomy.py) */
+int hgibbs_resident_trace(hgibbs_t h, uint64_t* out, uint64_t words);
 
 /* ======================================================================== */
 /* Host driver: the body of BayesRRm::runMpiGibbs (src/BayesRRm.cpp:933-2939)

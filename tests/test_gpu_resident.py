@@ -121,8 +121,9 @@ def test_engines_agree(oracle):
 
 
 def test_geometry_does_not_change_the_chain(oracle):
-    """Sums over workgroups are integers (Gram terms; raw dots as fixed point): the chain is bit-identical whatever the
-    number of workgroups, tiles per workgroup or window."""
+    """Sums over workgroups are integers (Gram terms; raw dots as fixed point), so the chain does not depend on the order
+    in which workgroups arrive; the number of workgroups, tiles per workgroup and the window only move the roundings of the
+    dots (a workgroup's part is rounded to the fixed-point grid): components identical, floating point far inside the tolerance."""
     M, N = 500, 8000
     bed, y = make_case(M, N, seed=9)
     outs = []
@@ -139,7 +140,7 @@ def test_geometry_does_not_change_the_chain(oracle):
         outs.append((beta, comp, acum))
     for o in outs[1:]:
         assert np.array_equal(o[1], outs[0][1])
-        assert close(o[0], outs[0][0], 1e-12) and close(o[2], outs[0][2], 1e-12)
+        assert close(o[0], outs[0][0], 1e-10) and close(o[2], outs[0][2], 1e-10)
 
 
 def test_refused_where_it_does_not_apply(oracle):
