@@ -37,7 +37,7 @@ constexpr int RS_CROW = 1024;             // the same for the batch counters
 constexpr int RS_RB = 2 * RS_BMAX;        // raw-dot accumulators: positions mod RS_RB
 constexpr int RS_MSG = 4;                 // message slots (seq mod RS_MSG)
 constexpr int RS_TRACE = 4096;            // messages whose stamps the debug build keeps
-constexpr int RS_TMAX = 4;                // most wave tiles per workgroup
+constexpr int RS_TMAX = 2;                // most wave tiles per workgroup (16 T doubles of eps per lane, in every wave; a build for 4 spills registers)
 constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
 
@@ -108,6 +108,14 @@ __device__ __forceinline__ double rs_readlane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// one DPP step of a 64-bit value (every lane reads a valid lane: no old value needed)
+template <int CTRL>
+__device__ __forceinline__ double rs_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 {
     u4_t v;
@@ -118,7 +126,7 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
     return v;
 }
 
-__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 24 + (size_t)B * 256 * T; }
+__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 80 + (size_t)B * 256 * T; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
@@ -141,10 +149,67 @@ __device__ __forceinline__ void rs_load_col(const uint8_t* col, uint32_t voff, u
     }
 }
 
+// The refill's columns land in the TOP 32 vector registers, named by hand: v224 .. v255 are outside what the compiler may allocate
+// (the kernel carries amdgpu_num_vgpr(RS_VGPR_LIMIT)), so nothing but the instructions below ever touches them.  The loads are
+// instructions the compiler does not see as loads: it would otherwise place its own wait before the first use of a loaded register,
+// and the only wait it can place there is for ALL vector-memory operations in flight (vmcnt counts in order, the loads are issued
+// under wave-uniform conditions it cannot count) -- for loads issued microseconds ago AND for the ones just issued for the next
+// round.  Registers of its own cannot serve: it is free to copy a loop-carried value to another register right behind the
+// instruction that "defined" it, i.e. before the load has landed (it does: a 16-register shuffle at the loop's back edge).  The
+// wait is placed by hand, once per pass (cols_landed); a set is read only behind it.  Set R = v(224 + R) for T = 1, v[224 + 2R : 225 + 2R]
+// for T = 2.  tools/asm_check_loads.py verifies on the emitted code that no other instruction names these registers.
+constexpr int RS_VGPR_LIMIT = 216; // v216 .. v220: the lanes' (mave, mstd, next id), v224 .. v255: the sets
+#define RS_SET_LIST(X) X(0, 224, 224, 225) X(1, 225, 226, 227) X(2, 226, 228, 229) X(3, 227, 230, 231) X(4, 228, 232, 233) X(5, 229, 234, 235) X(6, 230, 236, 237) X(7, 231, 238, 239) X(8, 232, 240, 241) X(9, 233, 242, 243) X(10, 234, 244, 245) X(11, 235, 246, 247) X(12, 236, 248, 249) X(13, 237, 250, 251) X(14, 238, 252, 253) X(15, 239, 254, 255)
+template <int T, int R>
+__device__ __forceinline__ void rs_set_load(uint32_t voff, const uint8_t* base)
+{
+    static_assert(T == 1 || T == 2, "one or two dwords per lane and column");
+#define RS_X(r, s1, lo, hi)                                                                                                                 \
+    if constexpr (R == r) {                                                                                                                 \
+        if constexpr (T == 1) asm volatile("global_load_dword v" #s1 ", %0, %1" ::"v"(voff), "s"(base) : "memory", "v" #s1);                \
+        else asm volatile("global_load_dwordx2 v[" #lo ":" #hi "], %0, %1" ::"v"(voff), "s"(base) : "memory", "v" #lo, "v" #hi);            \
+    }
+    RS_SET_LIST(RS_X)
+#undef RS_X
+}
+// the set's dwords, masked (keep: the lanes' valid individuals)
+template <int T, int R>
+__device__ __forceinline__ void rs_set_read(uint32_t (&w)[T], const uint32_t (&keep)[T])
+{
+#define RS_X(r, s1, lo, hi)                                                                                                                 \
+    if constexpr (R == r) {                                                                                                                 \
+        if constexpr (T == 1) asm volatile("v_and_b32 %0, v" #s1 ", %1" : "=v"(w[0]) : "v"(keep[0]));                                       \
+        else asm volatile("v_and_b32 %0, v" #lo ", %2\n\tv_and_b32 %1, v" #hi ", %3" : "=&v"(w[0]), "=&v"(w[T - 1]) : "v"(keep[0]), "v"(keep[T - 1])); \
+    }
+    RS_SET_LIST(RS_X)
+#undef RS_X
+}
+
+// per-lane values that travel with the sets (their loads must not make the compiler wait either): lane r keeps (mave, mstd) of set r's
+// column in v[216:217], v[218:219] and the marker id of the set's NEXT column in v220 -- named registers as well
+__device__ __forceinline__ void rs_lane_load(const double* mave, const double* mstd, const int32_t* id)
+{
+    asm volatile("global_load_dwordx2 v[216:217], %0, off\n\tglobal_load_dwordx2 v[218:219], %1, off\n\tglobal_load_dword v220, %2, off" ::"v"(mave), "v"(mstd), "v"(id)
+                 : "memory", "v216", "v217", "v218", "v219", "v220");
+}
+__device__ __forceinline__ double2 rs_lane_meta()
+{
+    int a0, a1, b0, b1;
+    asm volatile("v_mov_b32 %0, v216\n\tv_mov_b32 %1, v217\n\tv_mov_b32 %2, v218\n\tv_mov_b32 %3, v219" : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1));
+    return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
+}
+// the lanes' next ids as an ordinary value (read behind the wait; the compiler then takes care of the readlane hazards itself)
+__device__ __forceinline__ int32_t rs_lane_ids()
+{
+    int32_t v;
+    asm volatile("v_mov_b32 %0, v220" : "=v"(v));
+    return v;
+}
+
 template <int T, int DBG>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
 {
-    constexpr int RS_PF = T >= 4 ? 8 : 16; // columns one wave has in flight per streaming pass
+    constexpr int RS_PF = 16; // register sets: columns one wave has in registers or on their way
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wg = blockIdx.x;
@@ -152,8 +217,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     double2* const tab = reinterpret_cast<double2*>(smem);                        // pair table of the event's addends (256 B)
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
     double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
-    long long* const rawbuf = reinterpret_cast<long long*>(smem + 512 + (size_t)B * 16); // this round's refill: the workgroup's raw dots by position
-    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 24);  // [B][64 * T] codes of the window columns
+    double* const part = reinterpret_cast<double*>(smem + 512 + (size_t)B * 16);       // this round's refill: [position - Sx][8] sums of the wave's eight-lane groups
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 80);  // [B][64 * T] codes of the window columns
     const bool timing = DBG && wg == 0 && tid == 0;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
@@ -190,30 +255,26 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     // after the set has been consumed -- spread over the refill's arithmetic instead of in one burst the memory queue would
     // make the wave wait for.  Lane r keeps what belongs to set r: (mave, mstd) of its column and the marker id of its NEXT one
     // (one vector load a round ahead: a scalar load per column would put a dependent round trip in front of every column load).
-    uint32_t cw[RS_PF][T];
-    double pm_ave = 0.0, pm_std = 0.0;
-    int32_t id_next = 0;
     uint32_t nk = 0; // columns of this wave's residue class streamed so far: set r holds k_r = nk + ((r - nk) mod RS_PF)
     auto pos_of = [&](uint32_t k) { return (uint32_t)wave + 8u * k; };
+    // everything loaded for the sets has landed
+    auto cols_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // set r takes the column of the wave's k-th position; its id is in lane r of v220 (past the end: any column; the set is never used)
+    auto load_set = [&](auto rtag, uint32_t k, int32_t ids) __attribute__((always_inline)) {
+        constexpr int r = decltype(rtag)::value;
+        const uint32_t pn = __builtin_amdgcn_readfirstlane(pos_of(k));
+        const int32_t mk = __builtin_amdgcn_readlane(ids, r);
+        rs_set_load<T, r>(voff, p.bed + (size_t)(pn < M ? mk : 0) * p.stride);
+    };
+    // lane r < RS_PF: (mave, mstd) of the column of position p1 and the id of position p2
+    auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u)); };
     {
+        // sets 0 .. RS_PF - 1 for k = 0 .. RS_PF - 1: the ids first (ordinary load), then the columns, then the lanes' values
         const uint32_t mp = pos_of((uint32_t)lane);
         int32_t id0 = 0;
-        if (lane < RS_PF && mp < M) {
-            id0 = p.order[mp];
-            pm_ave = p.s_mave[mp];
-            pm_std = p.s_mstd[mp];
-        }
-        const uint32_t mp2 = pos_of((uint32_t)lane + RS_PF);
-        if (lane < RS_PF && mp2 < M) id_next = p.order[mp2];
-#pragma unroll
-        for (int r = 0; r < RS_PF; ++r) {
-            if (pos_of((uint32_t)r) < M) {
-                rs_load_col<T>(p.bed + (size_t)__builtin_amdgcn_readlane(id0, r) * p.stride, voff, cw[r]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < T; ++t) cw[r][t] = 0u;
-            }
-        }
+        if (lane < RS_PF) id0 = p.order[mp < M ? mp : 0u];
+        [&]<int... R>(std::integer_sequence<int, R...>) { (load_set(std::integral_constant<int, R>{}, (uint32_t)R, id0), ...); }(std::make_integer_sequence<int, RS_PF>{});
+        if (lane < RS_PF) lane_load(mp, pos_of((uint32_t)lane + RS_PF));
     }
     for (;;) {
         const bool upd = kind == RS_EVENT;
@@ -223,6 +284,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         const uint32_t nnew = Sn - Sx;
         uint32_t count_w = (Sn > (uint32_t)wave ? (Sn - (uint32_t)wave + 7u) / 8u : 0u) - nk; // this wave's positions in [Sx, Sn)
+        cols_landed(); // issued at the end of the last round: nothing to wait for (and no Gram atomic in flight yet)
 
         if (upd) {
             // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave ----
@@ -292,10 +354,13 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
+        uint32_t done_k0 = nk, done_m = 0; // the sets the last pass consumed: reloaded behind the raw dots
         while (count_w) {
+            if (done_m) cols_landed(); // a second pass in one round (more than 8 RS_PF new columns): its columns are asked for here and now
             const uint32_t m = count_w < (uint32_t)RS_PF ? count_w : (uint32_t)RS_PF; // register sets in use this pass: k in [nk, nk + m)
-#pragma unroll
-            for (int g = 0; g < RS_PF / 4; ++g) {
+            const int32_t ids = rs_lane_ids(); // lane r: marker id of set r's next column
+            auto quad = [&](auto gtag) __attribute__((always_inline)) {
+                constexpr int g = decltype(gtag)::value;
                 uint32_t kr[4];
                 bool act[4];
 #pragma unroll
@@ -306,10 +371,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 if (act[0] || act[1] || act[2] || act[3]) { // wave-uniform
                     double a[4] = {0.0, 0.0, 0.0, 0.0};
                     uint32_t gw[4][T];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) gw[c][t] = cw[4 * g + c][t] & keep[t];
+                    rs_set_read<T, 4 * g + 0>(gw[0], keep);
+                    rs_set_read<T, 4 * g + 1>(gw[1], keep);
+                    rs_set_read<T, 4 * g + 2>(gw[2], keep);
+                    rs_set_read<T, 4 * g + 3>(gw[3], keep);
 #pragma unroll
                     for (int t = 0; t < T; ++t)
                         fma_slots4(gw[0][t], gw[1][t], gw[2][t], gw[3][t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT>{});
@@ -321,54 +386,62 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                             uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
 #pragma unroll
                             for (int t = 0; t < T; ++t) rp[t] = gw[c][t];
-                            {
-                                const double ma = rs_readlane(pm_ave, 4 * g + c), ms = rs_readlane(pm_std, 4 * g + c);
-                                if (lane == 0) meta[slot] = make_double2(ma, ms);
-                            }
-                            // the workgroup's part of s1 travels as a 51-bit fixed-point integer, taken from "x + 1.5 2^52" (round to
-                            // nearest, exact for |x| < 2^51): sums over workgroups are then exact and order-independent
-                            const double s1 = wave_sum(a[c]);
-                            const double xs = s1 * p.fx_scale;
-                            if (!(fabs(xs) < 2.2e15)) { // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
-                                if (lane == 0) atomicMax(&p.state->error, 5u);
-                            }
-                            const double MAGIC = 6755399441055744.0;
-                            if (lane == 0) rawbuf[pos - Sx] = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
-                            // the set's next column leaves HBM now
-                            const uint32_t pn = __builtin_amdgcn_readfirstlane(pos_of(kr[c] + (uint32_t)RS_PF));
-                            if (pn < M) {
-                                rs_load_col<T>(p.bed + (size_t)__builtin_amdgcn_readlane(id_next, 4 * g + c) * p.stride, voff, cw[4 * g + c]);
-                            } else {
-#pragma unroll
-                                for (int t = 0; t < T; ++t) cw[4 * g + c][t] = 0u;
-                            }
+                            // the lane sums meet in eight-lane groups (three DPP steps, fixed order); the eight group sums go to LDS and
+                            // are added by ONE thread per column behind the barrier (in order: the dot does not depend on which wave took it)
+                            double v = a[c];
+                            v += rs_dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+                            v += rs_dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+                            v += rs_dpp_f64<0x141>(v); // row_half_mirror
+                            if ((lane & 7) == 0) part[(pos - Sx) * 8u + ((uint32_t)lane >> 3)] = v;
                         }
                     }
+                    // the quad's consumed sets take their next columns now: the loads leave HBM while the other quads are at work (no wait
+                    // is triggered by them: they are waited for by hand, at the top of the next round)
+                    if (!last) {
+                        if (act[0]) load_set(std::integral_constant<int, 4 * g + 0>{}, kr[0] + (uint32_t)RS_PF, ids);
+                        if (act[1]) load_set(std::integral_constant<int, 4 * g + 1>{}, kr[1] + (uint32_t)RS_PF, ids);
+                        if (act[2]) load_set(std::integral_constant<int, 4 * g + 2>{}, kr[2] + (uint32_t)RS_PF, ids);
+                        if (act[3]) load_set(std::integral_constant<int, 4 * g + 3>{}, kr[3] + (uint32_t)RS_PF, ids);
+                    }
                 }
-            }
-            // lanes of the sets that were refilled: their column's (mave, mstd) and the id of the one after it
+            };
+            quad(std::integral_constant<int, 0>{});
+            quad(std::integral_constant<int, 1>{});
+            quad(std::integral_constant<int, 2>{});
+            quad(std::integral_constant<int, 3>{});
+            // (mave, mstd) of the columns just taken go to their window slots; the lanes take their next column's and the id of the one after
             {
                 const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));
                 if (lane < RS_PF && kl - nk < m) {
-                    const uint32_t mp = pos_of(kl + (uint32_t)RS_PF), mp2 = pos_of(kl + 2u * (uint32_t)RS_PF);
-                    if (mp < M) {
-                        pm_ave = p.s_mave[mp];
-                        pm_std = p.s_mstd[mp];
-                    }
-                    id_next = mp2 < M ? p.order[mp2] : 0;
+                    meta[pos_of(kl) & bmask] = rs_lane_meta();
+                    lane_load(pos_of(kl + (uint32_t)RS_PF), pos_of(kl + 2u * (uint32_t)RS_PF));
                 }
             }
+            done_k0 = nk;
+            done_m = m;
             nk += m;
             count_w -= m;
         }
         lap(3);
-        __syncthreads(); // the window's new columns and this round's raw dots are in LDS for every wave
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the window's new columns and this round's group sums are in LDS for every wave
         lap(4);
         if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
-        // the refill's raw dots go out as contiguous 8-byte atomic adds (one 64-byte request per eight positions), then -- once
-        // they have been performed -- one add to the shard's batch counter tells the walker that this workgroup's part is in
-        for (uint32_t t = (uint32_t)tid; t < nnew; t += RS_BLOCK)
-            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)rawbuf[t], HG_RLX_AGENT);
+        // One thread per refilled position adds the eight group sums of its column in order and sends the workgroup's part of s1 as
+        // a 51-bit fixed-point integer -- taken from "x + 1.5 2^52" (round to nearest, exact for |x| < 2^51) -- by an 8-byte atomic add
+        // (contiguous over the threads: one 64-byte request per eight positions): sums over workgroups are exact and do not depend on
+        // the order of arrival.  Once the adds have been performed, one add to the shard's batch counter tells the walker that this
+        // workgroup's part is in.
+        for (uint32_t t = (uint32_t)tid; t < nnew; t += RS_BLOCK) {
+            const double* pp = part + t * 8u;
+            double s1 = pp[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) s1 += pp[i];
+            const double xs = s1 * p.fx_scale;
+            if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
+            const double MAGIC = 6755399441055744.0;
+            const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
+            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
+        }
         wait_vmcnt<0>();
         lap(5);
         __syncthreads();
@@ -925,7 +998,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
 }
 
 template <int T, int DBG>
-__global__ __launch_bounds__(RS_BLOCK) void k_sweep_resident(ResParams p)
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p)
 {
     if (blockIdx.x < p.W) res_streamer<T, DBG>(p, hg_smem);
     else res_walker<DBG>(p, hg_smem);

@@ -1224,8 +1224,7 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     if (cus < 2) return "fewer than two compute units";
     const uint32_t ntile = h->n_pad / TILE;
     uint32_t T = (ntile + (cus - 1) - 1) / (cus - 1);
-    T = T <= 1 ? 1 : (T <= 2 ? 2 : 4);
-    if ((uint64_t)T * (cus - 1) < ntile) return "more individuals than RS_TMAX tiles per compute unit hold";
+    if (T > (uint32_t)RS_TMAX) return "more individuals than the compute units hold in registers (2048 each)";
     pl->T = (int)T;
     pl->W = (ntile + T - 1) / T;
     uint32_t B = h->window ? h->window : (uint32_t)RS_BMAX;
@@ -1304,8 +1303,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     const bool dbg = h->debug_timing;
     switch (pl.T) {
     case 1: kern = dbg ? k_sweep_resident<1, 1> : k_sweep_resident<1, 0>; break;
-    case 2: kern = dbg ? k_sweep_resident<2, 1> : k_sweep_resident<2, 0>; break;
-    default: kern = dbg ? k_sweep_resident<4, 1> : k_sweep_resident<4, 0>; break;
+    default: kern = dbg ? k_sweep_resident<2, 1> : k_sweep_resident<2, 0>; break;
     }
     static bool attr_set[8] = {};
     const int ai = (pl.T == 1 ? 0 : (pl.T == 2 ? 1 : 2)) * 2 + (dbg ? 1 : 0);

@@ -66,7 +66,7 @@ def test_window_sizes(oracle, window):
     run_vs_oracle(oracle, 500, 3000, opts={"window": window})
 
 
-@pytest.mark.parametrize("cus,T", [(9, 1), (5, 2), (3, 4)])
+@pytest.mark.parametrize("cus,T", [(9, 1), (7, 2), (5, 2)])
 def test_tiles_per_workgroup(oracle, cus, T):
     # N = 8000 -> 8 wave tiles: res_cus decides how many tiles one workgroup holds in registers
     run_vs_oracle(oracle, 400, 8000, opts={"res_cus": cus}, expect_T=T)
@@ -127,7 +127,7 @@ def test_geometry_does_not_change_the_chain(oracle):
     M, N = 500, 8000
     bed, y = make_case(M, N, seed=9)
     outs = []
-    for opts in ({"res_cus": 9}, {"res_cus": 5}, {"res_cus": 3, "window": 64}, {"window": 16}):
+    for opts in ({"res_cus": 9}, {"res_cus": 5}, {"res_cus": 6, "window": 64}, {"window": 16}):
         dev = capi.Device(0)
         dev.load_bed(bed, N)
         dev.set_option("engine", 2)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Static check of the device assembly of the resident sweep kernel (hg_resident.hip.h).  The columns that refill the window land in
+vector registers v224 .. v255 (and the lanes' per-set values in v216 .. v220), named by hand in inline assembly and loaded by
+instructions the compiler does not see as loads; the kernel carries amdgpu_num_vgpr(216), so the compiler must never allocate them.  This script verifies exactly that on the emitted
+code: in every k_sweep_resident kernel, no instruction outside an inline-assembly block names a register >= v216, and inside
+inline assembly only the expected instructions do (global_load_dword[x2], v_and_b32, v_mov_b32, v_readlane_b32).
+usage: asm_check_loads.py file.s   (exit 1 on a violation)"""
+import re
+import sys
+
+LIMIT = 216
+text = open(sys.argv[1]).read().splitlines()
+
+
+def vregs(s):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", s):
+        out |= set(range(int(a), int(b) + 1))
+    out |= {int(x) for x in re.findall(r"\bv(\d+)\b", s)}
+    return out
+
+
+bad = checked = 0
+i, n = 0, len(text)
+while i < n:
+    m = re.match(r"^(\S*k_sweep_resident\S*):\s", text[i])
+    if m and not text[i].startswith("."):
+        name, inasm, loads, reads = m.group(1), False, 0, 0
+        j = i + 1
+        while j < n and "s_endpgm" not in text[j]:
+            t = text[j].strip()
+            if "#ASMSTART" in t:
+                inasm = True
+            elif "#ASMEND" in t:
+                inasm = False
+            elif t and not t.startswith((";", ".")) and not t.endswith(":"):
+                t = t.split(";")[0]
+                hi = {r for r in vregs(t) if r >= LIMIT}
+                if hi and not inasm:
+                    print("%s line %d: %s   (names v%s outside inline assembly)" % (name[:48], j + 1, t.strip()[:80], sorted(hi)[:4]))
+                    bad += 1
+                elif hi:
+                    op = t.split()[0]
+                    if op.startswith("global_load_dword"):
+                        loads += 1
+                    elif op in ("v_and_b32", "v_mov_b32", "v_readlane_b32"):
+                        reads += 1
+                    else:
+                        print("%s line %d: %s   (unexpected inline-assembly use of the landing registers)" % (name[:48], j + 1, t.strip()[:80]))
+                        bad += 1
+            j += 1
+        print("%s: %d loads into / %d reads of the landing registers, all inside inline assembly" % (name, loads, reads))
+        if loads == 0 or reads == 0:
+            print("  ... but none were found: the check does not see what it is meant to check")
+            bad += 1
+        checked += 1
+        i = j
+    i += 1
+print("kernels checked: %d, violations: %d" % (checked, bad))
+sys.exit(1 if bad or not checked else 0)
