@@ -53,6 +53,7 @@ struct ResMsg {
 struct ResState { // device -> host, written by the walker at the end of the sweep
     uint32_t cursor, rng_idx, error, pad;
     unsigned long long rounds, events, advances, nnz, chunks, refolds;
+    unsigned long long shader_ticks, wall_ticks; // s_memtime and 100 MHz wall clock over the walker's life: the clock the chip held
     unsigned long long t[16]; // 100 MHz ticks: walker [0] fold [1] collect [2] evaluate [3] scan + draw [4] announce + outputs + prefetch;
                               // streaming workgroup 0: [8] poll [9] update [10] Gram [11] refill dots [12] barrier [13] raw atomics + drain [14] barrier + count [15] prefetch issue
 };
@@ -91,7 +92,8 @@ struct ResParams {
     ResState* state;
     double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale), |.| < 2^51 per workgroup
     unsigned long long timeout;  // 100 MHz ticks a spin may last
-    volatile unsigned long long* progress; // pinned host memory: [0] walker (round << 8 | stage), [1] streaming workgroup 0 (message << 8 | stage): what the host reports when its deadline passes
+    unsigned long long* progress; // device memory: [0] walker (round << 8 | stage), [1] streaming workgroup 0 (message << 8 | stage): what the host
+                                  // reports when its deadline passes (a store to host memory here would put a PCIe round trip in front of the next barrier)
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
 };
@@ -510,6 +512,9 @@ struct WalkShared {
     uint32_t* batch; // refill batch (= message number) that streamed the slot's column
     uint32_t* gpart; // [RS_NSH][RS_BMAX] the shards' Gram sums of the event being collected
     unsigned long long* rprev; // [RS_RB] sum over the shards of the raw-dot words as last seen (they only ever grow)
+    double* tq;     // [MT_BUF] per word of the staged generator blocks: the largest max_l (logL_l - logL_0) that cannot give an event
+    double* qtab;   // [2][HT_LDS]: per (group, component) c = logpi - hlog - logpi_0 and r = 1 / (2 sigmaE denom)
+    uint16_t* crank; // [RS_BMAX] rank of the window position among the markers that take a uniform (adaV), this walk
     uint8_t* ada;
     uint8_t* fdone; // the slot's raw dot has arrived
     unsigned char* end;
@@ -519,7 +524,7 @@ struct WalkShared {
     uint32_t* fl;   // 64 words of flags
     int32_t* lcass; // [256]
 };
-enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7 };
+enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7, WF_CAND = 8, WF_NADA = 9 };
 enum { WD_DBETA = 0, WD_BNEW = 1, WD_PROB = 2 };
 
 __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
@@ -538,6 +543,8 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.num = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.ebuf = reinterpret_cast<double*>(q); q += (size_t)RS_BLOCK * 8;
     s.rprev = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
+    s.tq = reinterpret_cast<double*>(q); q += (size_t)MT_BUF * 8;
+    s.qtab = reinterpret_cast<double*>(q); q += (size_t)2 * HT_LDS * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
     s.marker = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
     s.grp = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
@@ -545,6 +552,7 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.gpart = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_NSH * RS_BMAX * 4;
     s.fl = reinterpret_cast<uint32_t*>(q); q += 64 * 4;
     s.lcass = reinterpret_cast<int32_t*>(q); q += 256 * 4;
+    s.crank = reinterpret_cast<uint16_t*>(q); q += (size_t)RS_BMAX * 2;
     s.bigf = q; q += RS_BLOCK;
     s.ada = q; q += B;
     s.fdone = q; q += B;
@@ -563,7 +571,8 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     const bool lds_tab = p.GK <= HT_LDS;
     const WalkShared sh = walk_carve(smem, B);
     const uint32_t EV = (uint32_t)RS_BLOCK / (uint32_t)K; // markers evaluated per chunk: one thread per (marker, component)
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tmark = DBG ? wall_clock64() : 0ull;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = wall_clock64();
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = DBG ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
         if (DBG && tid == 0) {
             const unsigned long long now = wall_clock64();
@@ -581,6 +590,21 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     if (lds_tab)
         for (int i = tid; i < 4 * p.GK; i += RS_BLOCK) sh.htab[(i / p.GK) * HT_LDS + (i % p.GK)] = p.denom[i];
     for (int i = tid; i < 256; i += RS_BLOCK) sh.lcass[i] = 0;
+    // tq[i]: with prob = the uniform of generator word i, no event iff prob <= 1 / sum_l exp(d_l) (d_l = logL_l - logL_0, d_0 = 0,
+    // :1883-1921), which holds whenever (K - 1) exp(max_l d_l) <= 1 / prob - 1: max_l d_l <= log((1 / prob - 1) / (K - 1)).  The
+    // margin covers the roundings of the quick form of d_l below; a marker beyond it is decided by the exact arithmetic.
+    auto stage_tq = [&](int lo, int hi) {
+        for (int i = lo + tid; i < hi; i += RS_BLOCK) {
+            const double prob = (double)mt_temper(sh.mt[i]) * (1.0 / 4294967296.0);
+            sh.tq[i] = log((1.0 / prob - 1.0) / (double)(K - 1)) - 1e-9;
+        }
+    };
+    if (lds_tab)
+        for (int i = tid; i < p.GK; i += RS_BLOCK) {
+            const int g0 = (i / K) * K;
+            sh.qtab[i] = (p.logpi[i] - p.hlog[i]) - p.logpi[g0];
+            sh.qtab[HT_LDS + i] = (i % K) ? p.i_2sigE / p.denom[i] : 0.0;
+        }
     for (int i = tid; i < RS_RB; i += RS_BLOCK) sh.rprev[i] = 0ull;
     if (tid < 64) sh.fl[tid] = 0u;
     auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
@@ -617,6 +641,8 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0;
     unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0;
     prefetch(0u, Sx, 0u);
+    __syncthreads();
+    stage_tq(0, MT_N);
     __syncthreads();
 
     // Refill batches all workgroups have completed (their raw dots are summed in racc): wave 0 reads the shards' counters.
@@ -673,7 +699,9 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         // generator: the next block exists before a round can run into it
         if (!has_next && rpos + B + 96u > (uint32_t)MT_N) {
             mt_next_block(sh.mt, tid);
+            stage_tq(MT_N, MT_BUF);
             has_next = true;
+            __syncthreads();
         }
         // 1. Gram terms of the window columns behind the last event (the streaming workgroups' first job after a message): wave s
         // polls shard s's row, 16 bytes per lane; every word in use must carry the shard's full arrival count
@@ -720,6 +748,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             }
         }
         pendG = false;
+        if (tid == 0) sh.fl[WF_CAND] = 0xffffffffu;
         __syncthreads();
         lap(1);
         if (DBG && tid == 0) p.trace[1 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
@@ -728,7 +757,11 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             break;
         }
 
-        // 3. the walk: posterior of a chunk of markers in parallel, then wave 0 consumes the stream in marker order
+        // 3. The walk.  Every position of the window that has its dot is tested in parallel, one thread each, with a bound that needs
+        // no exponential: "this marker cannot be an event" (see stage_tq).  The first position that does not pass -- a marker whose
+        // effect is non-zero (it WILL change), or one too close to call -- is decided by wave 0 with the exact arithmetic of the
+        // reference (all thresholds of its marker, :1883-1921, the component, the draw, a7); if that says "no event" after all, the
+        // next candidate is looked at.  Acum of the markers that pass is computed behind the message (step 5).
         if (tid == 0) p.progress[0] = (n_rounds << 8) | 2u;
         uint32_t base = C;
         bool found = false;
@@ -747,86 +780,72 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                 if (sh.fl[WF_ABORT]) break;
                 lap(0);
             }
-            const uint32_t nevl = (F - base < EV) ? F - base : EV;
+            const uint32_t nA = F - base; // <= B <= 256 positions: threads 0 .. nA - 1
             ++n_chunks;
             if (tid == 0) p.progress[0] = (n_rounds << 8) | 4u;
+            bool cand = false;
+            uint32_t myrank = 0;
             {
-                const uint32_t jj = (uint32_t)tid / (uint32_t)K;
-                const int l = (int)((uint32_t)tid % (uint32_t)K);
-                if (jj < nevl) {
-                    const uint32_t slot = (base + jj) & bmask;
-                    if (sh.ada[slot]) {
-                        const int g0 = sh.grp[slot] * K;
-                        const double num = (sh.dpr[slot] + sh.dp[slot]) + sh.bold[slot] * p.n_minus_1;
-                        const double L0 = tabv(1, g0);
-                        double L = L0;
-                        if (l > 0) {
-                            const double mk = num / tabv(0, g0 + l);
-                            L = tabv(1, g0 + l) - tabv(2, g0 + l) + mk * num * p.i_2sigE;
-                        }
-                        const double d = L - L0;
-                        sh.ebuf[tid] = exp(d);
-                        sh.bigf[tid] = (uint8_t)((l >= 1 && fabs(d) > 700.0) ? 1 : 0);
-                        if (l == 0) sh.num[slot] = num;
-                    }
+                const int wv = tid >> 6;
+                // rank among the markers that take a uniform: ballots of this wave's positions and of the waves before it
+                uint32_t before = 0;
+                unsigned long long am = 0ull;
+                for (int w = 0; w <= wv && w < 4; ++w) {
+                    const uint32_t jw = (uint32_t)(w * WAVE + lane);
+                    const bool a = jw < nA && sh.ada[(base + jw) & bmask] != 0;
+                    const unsigned long long m = __ballot(a);
+                    if (w < wv) before += (uint32_t)__popcll(m);
+                    else am = m;
                 }
-            }
-            __syncthreads();
-            if ((uint32_t)tid < nevl) {
-                const uint32_t slot = (base + (uint32_t)tid) & bmask;
-                if (sh.ada[slot]) {
-                    double sum = 0.0;
-                    bool big = false;
-                    for (int l = 0; l < K; ++l) {
-                        sum += sh.ebuf[(uint32_t)tid * (uint32_t)K + (uint32_t)l];
-                        big = big || sh.bigf[(uint32_t)tid * (uint32_t)K + (uint32_t)l] != 0;
+                if ((uint32_t)tid < nA) {
+                    const uint32_t slot = (base + (uint32_t)tid) & bmask;
+                    const bool ada = sh.ada[slot] != 0;
+                    const double bold = sh.bold[slot];
+                    myrank = before + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    sh.crank[tid] = (uint16_t)myrank;
+                    cand = bold != 0.0;
+                    if (ada) {
+                        const int g0 = sh.grp[slot] * K;
+                        const double num = (sh.dpr[slot] + sh.dp[slot]) + bold * p.n_minus_1;
+                        sh.num[slot] = num;
+                        const double n2 = num * num;
+                        double dmax = -1e300, dmin = 1e300;
+                        for (int l = 1; l < K; ++l) {
+                            double c, r;
+                            if (lds_tab) {
+                                c = sh.qtab[g0 + l];
+                                r = sh.qtab[HT_LDS + g0 + l];
+                            } else {
+                                c = (p.logpi[g0 + l] - p.hlog[g0 + l]) - p.logpi[g0];
+                                r = p.i_2sigE / p.denom[g0 + l];
+                            }
+                            const double d = c + n2 * r;
+                            dmax = d > dmax ? d : dmax;
+                            dmin = d < dmin ? d : dmin;
+                        }
+                        cand = cand || !(dmax <= sh.tq[rpos + myrank] && dmin >= -699.0);
                     }
-                    sh.thr0[slot] = big ? 0.0 : 1.0 / sum;
+                    if (cand) atomicMin(&sh.fl[WF_CAND], base + (uint32_t)tid);
+                    if ((uint32_t)tid == nA - 1u) sh.fl[WF_NADA] = myrank + (ada ? 1u : 0u);
                 }
             }
             __syncthreads();
             lap(2);
-
-            if (tid < WAVE) {
-                uint32_t pos = rpos, fq = 0u;
-                double fprob = 0.0;
-                bool stopped = false;
-                for (uint32_t cb = 0; cb < nevl && !stopped; cb += WAVE) {
-                    const bool valid = cb + (uint32_t)lane < nevl;
-                    const uint32_t slot = (base + cb + (uint32_t)lane) & bmask;
-                    const bool ada = valid && sh.ada[slot] != 0;
-                    const double bold = valid ? sh.bold[slot] : 0.0;
-                    const unsigned long long am = __ballot(ada);
-                    const uint32_t jeff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-                    double prob = 0.0;
-                    bool ev = valid && bold != 0.0;
-                    if (ada) {
-                        const uint32_t u = mt_temper(sh.mt[pos + jeff]);
-                        prob = (double)u * (1.0 / 4294967296.0);
-                        ev = ev || !(prob <= sh.thr0[slot]);
-                    }
-                    const unsigned long long em = __ballot(ev);
-                    const uint32_t nvalid = (nevl - cb < (uint32_t)WAVE) ? nevl - cb : (uint32_t)WAVE;
-                    if (em) {
-                        const uint32_t f = (uint32_t)(__ffsll((long long)em) - 1);
-                        const uint32_t used = (uint32_t)__popcll(am & ((f >= 63u) ? ~0ull : ((1ull << (f + 1u)) - 1ull)));
-                        pos += used;
-                        stopped = true;
-                        fq = base + cb + f;
-                        fprob = __shfl(prob, (int)f, 64);
-                    } else {
-                        pos += (uint32_t)__popcll(am & ((nvalid >= 64u) ? ~0ull : ((1ull << nvalid) - 1ull)));
-                    }
-                }
-                // the event: all thresholds of its marker (:1883-1921), the component, the draw (a7)
-                if (stopped) {
-                    const uint32_t slot = fq & bmask;
+            // the candidates in order, until one is an event
+            for (;;) {
+                const uint32_t qc = sh.fl[WF_CAND];
+                if (qc == 0xffffffffu) break; // uniform
+                if (tid < WAVE) {
+                    const uint32_t slot = qc & bmask;
                     const bool ada = sh.ada[slot] != 0;
-                    const double bold = sh.bold[slot], prob = fprob;
+                    const double bold = sh.bold[slot];
+                    const uint32_t upos = rpos + (uint32_t)sh.crank[qc - base]; // the marker's uniform (if it takes one)
+                    uint32_t pos = upos + (ada ? 1u : 0u);
                     int k = 0;
                     double bnew = 0.0;
                     uint32_t consumed = 0u, gerr = 0u;
-                    if (ada && !(prob <= sh.thr0[slot])) { // wave-uniform
+                    if (ada) { // wave-uniform
+                        const double prob = (double)mt_temper(sh.mt[upos]) * (1.0 / 4294967296.0);
                         const int g0 = sh.grp[slot] * K;
                         const double num = sh.num[slot];
                         double Lm = 0.0; // lane x < K: logL_x
@@ -855,11 +874,11 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                         k = K - 1;
                         double acum = 0.0;
                         bool fnd = false;
-                        for (int s = 0; s + 1 < K; ++s) {
-                            const double t = __shfl(thr, 8 * s, 64);
-                            acum = s ? acum + t : t;
+                        for (int sidx = 0; sidx + 1 < K; ++sidx) {
+                            const double t = __shfl(thr, 8 * sidx, 64);
+                            acum = sidx ? acum + t : t;
                             if (!fnd && prob <= acum) {
-                                k = s;
+                                k = sidx;
                                 fnd = true;
                             }
                         }
@@ -874,22 +893,36 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                         consumed = (uint32_t)__shfl((int)consumed, 0, 64);
                         gerr = (uint32_t)__shfl((int)gerr, 0, 64);
                     }
-                    pos += consumed;
+                    const bool is_ev = k != 0 || bold != 0.0;
                     if (lane == 0) {
-                        sh.fl[WF_FOUND] = 1u;
-                        sh.fl[WF_Q] = fq;
-                        sh.fl[WF_K] = (uint32_t)k;
-                        sh.fd[WD_BNEW] = bnew;
-                        sh.fd[WD_DBETA] = bold - bnew;
-                        if (gerr) sh.fl[WF_ERR] = gerr;
+                        if (is_ev) {
+                            sh.fl[WF_FOUND] = 1u;
+                            sh.fl[WF_Q] = qc;
+                            sh.fl[WF_K] = (uint32_t)k;
+                            sh.fl[WF_RPOS] = pos + consumed;
+                            sh.fd[WD_BNEW] = bnew;
+                            sh.fd[WD_DBETA] = bold - bnew;
+                            if (gerr) sh.fl[WF_ERR] = gerr;
+                        } else {
+                            sh.fl[WF_CAND] = 0xffffffffu; // too close to call, and no event: on to the next candidate
+                        }
                     }
                 }
-                if (lane == 0) sh.fl[WF_RPOS] = pos;
+                __syncthreads();
+                if (sh.fl[WF_FOUND]) break;
+                if (cand && base + (uint32_t)tid == qc) cand = false;
+                if (cand) atomicMin(&sh.fl[WF_CAND], base + (uint32_t)tid);
+                __syncthreads();
+            }
+            found = sh.fl[WF_FOUND] != 0u;
+            if (found) {
+                rpos = sh.fl[WF_RPOS];
+            } else {
+                rpos += sh.fl[WF_NADA];
+                base += nA;
             }
             __syncthreads();
-            rpos = sh.fl[WF_RPOS];
-            found = sh.fl[WF_FOUND] != 0u;
-            if (!found) base += nevl;
+            if (tid == 0) sh.fl[WF_CAND] = 0xffffffffu; // (for the next pass of the walk: set behind one barrier, used behind the next)
             lap(3);
         }
         if (sh.fl[WF_ABORT] || sh.fl[WF_ERR]) {
@@ -933,25 +966,59 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             ++n_adv;
         }
 
-        // 5. results of the consumed markers (:1892,:1899-1905,:1924-1925), then their slots go to the refill
-        for (uint32_t j = C + (uint32_t)tid; j < Cn; j += RS_BLOCK) {
-            const uint32_t slot = j & bmask;
-            const int marker = sh.marker[slot];
-            const bool isq = found && j == qpos;
-            if (DBG) { // the dot as streamed and its Gram corrections, by sweep position (tools/dbg_res.py)
-                p.trace[8 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dpr[slot]);
-                p.trace[9 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dp[slot]);
+        // 5. results of the consumed markers (:1892,:1899-1905,:1924-1925) -- Acum = 1 / sum_l exp(logL_l - logL_0) with the reference's
+        // arithmetic, one thread per (marker, component), off the chain: the streaming workgroups are busy with the message -- then
+        // their slots go to the refill
+        for (uint32_t b0 = C; b0 < Cn; b0 += EV) {
+            const uint32_t nevl = (Cn - b0 < EV) ? Cn - b0 : EV;
+            {
+                const uint32_t jj = (uint32_t)tid / (uint32_t)K;
+                const int l = (int)((uint32_t)tid % (uint32_t)K);
+                if (jj < nevl) {
+                    const uint32_t slot = (b0 + jj) & bmask;
+                    if (sh.ada[slot]) {
+                        const int g0 = sh.grp[slot] * K;
+                        const double num = sh.num[slot];
+                        const double L0 = tabv(1, g0);
+                        double L = L0;
+                        if (l > 0) {
+                            const double mk = num / tabv(0, g0 + l);
+                            L = tabv(1, g0 + l) - tabv(2, g0 + l) + mk * num * p.i_2sigE;
+                        }
+                        const double d = L - L0;
+                        sh.ebuf[tid] = exp(d);
+                        sh.bigf[tid] = (uint8_t)((l >= 1 && fabs(d) > 700.0) ? 1 : 0);
+                    }
+                }
             }
-            if (sh.ada[slot]) {
-                const int kk = isq ? kq : 0;
-                p.beta[marker] = isq ? bnew : 0.0;
-                p.comp[marker] = kk;
-                p.acum[marker] = sh.thr0[slot];
-                atomicAdd(&sh.lcass[sh.grp[slot] * K + kk], 1);
-            } else {
-                p.beta[marker] = 0.0;
-                p.acum[marker] = 1.0;
+            __syncthreads();
+            if ((uint32_t)tid < nevl) {
+                const uint32_t j = b0 + (uint32_t)tid;
+                const uint32_t slot = j & bmask;
+                const int marker = sh.marker[slot];
+                const bool isq = found && j == qpos;
+                if (DBG) { // the dot as streamed and its Gram corrections, by sweep position (tools/dbg_res.py)
+                    p.trace[8 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dpr[slot]);
+                    p.trace[9 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dp[slot]);
+                }
+                if (sh.ada[slot]) {
+                    double sum = 0.0;
+                    bool big = false;
+                    for (int l = 0; l < K; ++l) {
+                        sum += sh.ebuf[(uint32_t)tid * (uint32_t)K + (uint32_t)l];
+                        big = big || sh.bigf[(uint32_t)tid * (uint32_t)K + (uint32_t)l] != 0;
+                    }
+                    const int kk = isq ? kq : 0;
+                    p.beta[marker] = isq ? bnew : 0.0;
+                    p.comp[marker] = kk;
+                    p.acum[marker] = big ? 0.0 : 1.0 / sum;
+                    atomicAdd(&sh.lcass[sh.grp[slot] * K + kk], 1);
+                } else {
+                    p.beta[marker] = 0.0;
+                    p.acum[marker] = 1.0;
+                }
             }
+            __syncthreads();
         }
         if (tid == 0) {
             sh.fl[WF_FOUND] = 0u;
@@ -960,7 +1027,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         prefetch(Sx, Sn, seq);
         if (rpos >= (uint32_t)MT_N) { // the stream crossed into the next block: it becomes the current one
-            for (int i = tid; i < MT_N; i += RS_BLOCK) sh.mt[i] = sh.mt[MT_N + i];
+            for (int i = tid; i < MT_N; i += RS_BLOCK) {
+                sh.mt[i] = sh.mt[MT_N + i];
+                sh.tq[i] = sh.tq[MT_N + i];
+            }
             rpos -= (uint32_t)MT_N;
             has_next = false;
         }
@@ -992,8 +1062,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         st->nnz = n_nnz;
         st->chunks = n_chunks;
         st->refolds = n_refold;
+        st->shader_ticks = __builtin_amdgcn_s_memtime() - clk0;
+        st->wall_ticks = wall_clock64() - wall0;
         if (DBG)
-            for (int i = 0; i < 5; ++i) st->t[i] = tacc[i];
+            for (int i = 0; i < 8; ++i) st->t[i] = tacc[i];
     }
 }
 

@@ -152,7 +152,9 @@ struct hgibbs_ctx {
     ResMsg* res_msg = nullptr;
     ResState* res_state = nullptr;
     ResState* res_state_host = nullptr; // pinned
-    unsigned long long* res_progress = nullptr; // pinned, written by the kernel while it runs
+    unsigned long long* res_progress = nullptr; // device, written by the kernel while it runs
+    unsigned long long* res_progress_host = nullptr; // pinned copy, fetched on a second stream when the host's deadline passes
+    hipStream_t aux_stream = nullptr;
     unsigned long long* res_trace = nullptr; // [8][RS_TRACE], debug_timing
     double res_timeout_s = 2.0;
     double res_deadline_s = 0.0; // option res_deadline_ms: the host's deadline for a resident sweep (0 = derived)
@@ -572,7 +574,9 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMalloc(&h->res_msg, RS_MSG * sizeof(ResMsg)));
     HIP_TRY(hipMalloc(&h->res_state, sizeof(ResState)));
     HIP_TRY(hipHostMalloc(&h->res_state_host, sizeof(ResState)));
-    HIP_TRY(hipHostMalloc(&h->res_progress, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->res_progress, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(&h->res_progress_host, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&h->res_trace, (size_t)10 * RS_TRACE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->res_trace, 0, (size_t)10 * RS_TRACE * sizeof(unsigned long long)));
     *out = h;
@@ -596,7 +600,9 @@ int hgibbs_destroy(hgibbs_t h)
     if (h->desc_host) (void)hipHostFree(h->desc_host);
     if (h->scratch_host) (void)hipHostFree(h->scratch_host);
     if (h->res_state_host) (void)hipHostFree(h->res_state_host);
-    if (h->res_progress) (void)hipHostFree(h->res_progress);
+    if (h->res_progress) (void)hipFree(h->res_progress);
+    if (h->res_progress_host) (void)hipHostFree(h->res_progress_host);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->beta_host) (void)hipHostFree(h->beta_host);
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
@@ -1293,7 +1299,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.dbg = h->debug_timing ? 1 : 0;
     p.trace = h->res_trace;
     p.progress = h->res_progress;
-    for (int i = 0; i < 16; ++i) h->res_progress[i] = 0;
+    HIP_TRY(hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream));
 
     HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
@@ -1337,11 +1343,12 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             if (el > limit_s)
             {
-                if (std::getenv("HGIBBS_DEBUG"))
-                    for (int i = 2; i < 10; ++i) std::fprintf(stderr, "[hgibbs] progress[%d] = %llu\n", i, (unsigned long long)h->res_progress[i]);
+                for (int i = 0; i < 16; ++i) h->res_progress_host[i] = 0;
+                if (hipMemcpyAsync(h->res_progress_host, h->res_progress, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->aux_stream) == hipSuccess)
+                    (void)hipStreamSynchronize(h->aux_stream);
+                const unsigned long long* pr = h->res_progress_host;
                 return fail("hgibbs_sweep: the resident kernel has not come back after %.0f s: walker at round %llu stage %llu, streaming workgroup 0 at message %llu stage %llu", el,
-                            (unsigned long long)(h->res_progress[0] >> 8), (unsigned long long)(h->res_progress[0] & 255u), (unsigned long long)(h->res_progress[1] >> 8),
-                            (unsigned long long)(h->res_progress[1] & 255u));
+                            (unsigned long long)(pr[0] >> 8), (unsigned long long)(pr[0] & 255u), (unsigned long long)(pr[1] >> 8), (unsigned long long)(pr[1] & 255u));
             }
             if (el > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.5 ? 2000 : 50));
         }
@@ -1373,6 +1380,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.chunks = st.chunks;
     s.refolds = st.refolds;
     for (int i = 0; i < 16; ++i) s.ticks[i] = st.t[i];
+    s.shader_mhz = st.wall_ticks ? 100.0 * (double)st.shader_ticks / (double)st.wall_ticks : 0.0;
     {
         double r1[2];
         if (reduce_eps_all(h, r1)) return 1;
@@ -1672,6 +1680,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     h->stats.kernel_ms_avg = cnt_host->launches ? ms / (double)cnt_host->launches : 0.0;
     h->stats.engine = 1;
     h->stats.rounds = h->stats.events = h->stats.advances = h->stats.chunks = h->stats.refolds = 0;
+    h->stats.shader_mhz = 0.0;
     for (int i = 0; i < 16; ++i) h->stats.ticks[i] = 0;
     {
         // s2 of the columns without missing calls was the sum of eps at sweep start for the whole sweep: what the sum is now says

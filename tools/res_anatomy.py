@@ -31,14 +31,14 @@ for it in range(iters):
     ch.iterate()
     dt = time.perf_counter() - t0
     s = dev.sweep_stats()
-    print("it %d: %.1f ms wall, %.1f ms device, %d rounds (%d events, %d advances), %.2f us/round, %d chunks, %d refolds, %.3f M markers/s, drift %.2e"
-          % (it, dt * 1e3, s["device_ms"], s["rounds"], s["events"], s["advances"], s["device_ms"] * 1e3 / max(1, s["rounds"]),
+    print("[%.0f MHz] it %d: %.1f ms wall, %.1f ms device, %d rounds (%d events, %d advances), %.2f us/round, %d chunks, %d refolds, %.3f M markers/s, drift %.2e"
+          % (s["shader_mhz"], it, dt * 1e3, s["device_ms"], s["rounds"], s["events"], s["advances"], s["device_ms"] * 1e3 / max(1, s["rounds"]),
              s["chunks"], s["refolds"], M / dt / 1e6, s["eps_sum_drift"]))
 t = s["ticks"]
 n = max(1, s["rounds"])
 us = lambda x: x / 100.0 / n
-print("walker per round (us): fold %.2f  collect %.2f  evaluate %.2f  scan+draw %.2f  message+results+prefetch %.2f  | sum %.2f"
-      % (us(t[0]), us(t[1]), us(t[2]), us(t[3]), us(t[4]), us(sum(t[0:5]))))
+print("walker per round (us): fold %.2f  collect %.2f  evaluate [terms %.2f  barrier %.2f  sums %.2f]  scan+draw %.2f  message+results+prefetch %.2f  | sum %.2f"
+      % (us(t[0]), us(t[1]), us(t[5]), us(t[6]), us(t[2]), us(t[3]), us(t[4]), us(sum(t[0:7]))))
 print("streaming workgroup 0 per round (us): wait %.2f  update %.2f  gram %.2f  refill dots %.2f  barrier %.2f  raw atomics + drain %.2f  barrier + count %.2f  prefetch issue %.2f | sum %.2f"
       % (us(t[8]), us(t[9]), us(t[10]), us(t[11]), us(t[12]), us(t[13]), us(t[14]), us(t[15]), us(sum(t[8:16]))))
 
