@@ -170,6 +170,8 @@ struct SweepParams {
     double* totals;        // [ROWS_CAP]: rows summed over the slices, published per column group
     uint32_t* ticket;      // groups that have published their totals
     uint32_t* gticket;     // [MAX_GROUPS]: per group, workgroups that have stored their partials
+    uint32_t* entered;     // [8] words 32 apart: workgroups of the current launch that have read its descriptor (the drawing workgroup publishes
+                           // the next one only when all of them have: a workgroup dispatched late must not see the next launch's plan)
     uint32_t cols_per_group; // columns handled per blockIdx.y
     uint32_t batch_cap;      // gridDim.y * cols_per_group (LDS carve-up)
     uint32_t batch_limit;    // widest batch a launch may take (the batch option)

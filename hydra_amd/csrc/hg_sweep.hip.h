@@ -649,6 +649,21 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         for (int q = 0; q < MAX_SEG; ++q) n.seg_end[q] = want[q];
         n.carry_n = carry_next;
         n.carry_left = carry_left;
+        if (p.entered) { // every workgroup of THIS launch has read its descriptor (a late one needs only a slot: bounded wait all the same)
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                uint32_t e = 0u;
+                for (int x = 0; x < 8; ++x) e += __hip_atomic_load(p.entered + 32 * x, HG_RLX_AGENT);
+                if (e >= gridDim.x) break;
+                if (wall_clock64() - t0 > 300000000ull) {
+                    n.error = 3u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            for (int x = 0; x < 8; ++x) __hip_atomic_store(p.entered + 32 * x, 0u, HG_RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         *p.desc = n;
         { // the sweep's counters: a read-modify-write of their own, off the hand-over's path
             SweepCounters c = *p.counters;
@@ -864,6 +879,9 @@ __global__ __launch_bounds__(BLOCK, ((CPG <= 4 || (CPG <= 8 && SEG <= 2)) ? 3 : 
     constexpr int RB = group_rows(CPG, SEG, MG); // row block of one group in `partials`
     const SweepShared sh = sweep_lds_carve(hg_smem, p.batch_cap, p.cols_per_group, p.K, NR);
     const DescHead d = load_desc_head(p.desc);
+    // this workgroup has the launch's descriptor.  (The value added depends on loaded fields -- both terms are zero, which the
+    // compiler cannot know -- so the add cannot be issued before the descriptor's loads have returned.)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(p.entered + 32u * (blockIdx.x & 7u), 1u + (d.error >> 31) + (uint32_t)(d.seq >> 63), HG_RLX_AGENT);
     const bool pend = d.pend_marker[0] >= 0;
     const uint32_t remaining = (d.cursor < p.M) ? p.M - d.cursor : 0u;
     uint32_t nbs[SEG]; // cumulative ends of this launch's segments

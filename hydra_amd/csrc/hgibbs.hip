@@ -146,6 +146,7 @@ struct hgibbs_ctx {
 
     // resident engine (hg_resident.hip.h): one launch per sweep, individuals sharded over the compute units
     int engine = 0;           // option engine: 0 auto (resident where it applies), 1 batch engine (k_sweep_batch), 2 resident (refused where it does not apply)
+    bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
@@ -558,8 +559,8 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMemcpy(h->zig + 515, HG_ZIG_EXP_Y, 257 * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&h->desc, sizeof(SweepDesc) + sizeof(SweepCounters)));      // descriptor, then the sweep's counters
     HIP_TRY(hipHostMalloc(&h->desc_host, sizeof(SweepDesc) + sizeof(SweepCounters)));
-    HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_GROUPS) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->ticket, (16 + MAX_GROUPS + 256) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->ticket, 0, (16 + MAX_GROUPS + 256) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->totals, (size_t)ROWS_CAP * sizeof(double)));
     HIP_TRY(hipMalloc(&h->carry, (size_t)MAX_BATCH * sizeof(double)));
     HIP_TRY(hipMalloc(&h->ahead_raw, (size_t)2 * AHEAD_MAX * 2 * sizeof(double)));
@@ -1102,6 +1103,9 @@ int hgibbs_beta_sqnorm(hgibbs_t h, double* bsq_host)
 int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
 {
     if (!h || !name) return fail("hgibbs_set_option: null argument");
+    // an option that shapes the batch engine's launches asks for that engine (unless the caller has chosen one)
+    for (const char* o : {"cols_per_group", "slices", "gram_missing", "graph", "max_seg", "ext_limit", "gram", "carry", "ahead", "force_split", "chunk"})
+        if (!std::strcmp(name, o) && h->engine == 0) h->engine_pinned = true;
     if (!std::strcmp(name, "batch")) {
         if (value < 0 || value > MAX_BATCH) return fail("batch must be in [0,%d] (0 = auto)", MAX_BATCH);
         h->batch = (uint32_t)value;
@@ -1429,7 +1433,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     HIP_TRY(hipMemcpyAsync(h->adaV, adaV_host, (size_t)M, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->mt, rng->x, MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->cass, 0, (size_t)G * K * sizeof(int32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_GROUPS) * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ticket, 0, (16 + MAX_GROUPS + 256) * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->aticket, 0, (AHEAD_MAX / 2 + 4) * sizeof(uint32_t), h->stream));
     k_gather_meta<<<(M + 255) / 256, 256, 0, h->stream>>>(h->order, h->mave, h->mstd, h->beta, h->groups, h->adaV, h->counts, h->s_mave, h->s_mstd,
                                                        h->s_bold, h->s_ga, M);
@@ -1459,7 +1463,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     {
         const char* why = resident_plan(h, &plan);
         if (h->engine == 2 && why) return fail("hgibbs_sweep: the resident engine does not apply: %s", why);
-        if (h->engine == 1) plan.ok = false;
+        if (h->engine == 1 || (h->engine == 0 && h->engine_pinned)) plan.ok = false;
         if (std::getenv("HGIBBS_DEBUG"))
             std::fprintf(stderr, "[hgibbs] engine: %s%s%s\n", plan.ok ? "resident" : "batch", why ? " -- resident refused: " : "", why ? why : "");
     }
@@ -1513,6 +1517,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     p.partials = h->partials;
     p.ticket = h->ticket;
     p.gticket = h->ticket + 16;
+    p.entered = h->ticket + 16 + MAX_GROUPS;
     p.totals = h->totals;
     p.carry = h->carry;
     p.ahead_raw = h->ahead_raw;

@@ -73,11 +73,19 @@ def _run_vs_oracle(oracle, bed, y, N, opts, iters, mS=None, groups=None, seed=31
         assert close(st["sigmaG"], ref.arr("sigmaG")) and close(st["sigmaE"], ref.sigmaE) and close(st["mu"], ref.mu), what
         assert ch.last_nnz() == oracle.orc_chain_last_nnz(ref.h), what
         s = dev.sweep_stats()
-        assert s["accepted_markers"] == bed.shape[0] and s["working_launches"] <= s["launches"]
+        assert s["accepted_markers"] == bed.shape[0]
+        if s["engine"] == 1:
+            assert s["working_launches"] <= s["launches"]
+        else:  # the resident engine: one launch per sweep, rounds of its walker
+            assert s["launches"] == 1 and s["rounds"] >= 1
         tiles = max(tiles, s["tiles_per_workgroup_max"])
         streamed += s["streamed_columns"]
         carried += s["carried_columns"]
-    assert tiles >= min_tiles, "every workgroup streamed %d tile group(s): the multi-tile loop did not run" % tiles
+    if s["engine"] == 1:
+        assert tiles >= min_tiles, "every workgroup streamed %d tile group(s): the multi-tile loop did not run" % tiles
+    else:
+        assert opts.get("engine", 0) != 1, "the batch engine was asked for"
+
     dev.close()
     return {"tiles": tiles, "streamed": streamed, "carried": carried}
 
@@ -131,13 +139,15 @@ def test_large_shard_default_geometry_vs_oracle(oracle, N, miss_cols, max_seg, c
     _run_vs_oracle(oracle, bed, y, N, opts, iters=3)
 
 
-def test_grouped_mixture_multi_tile_vs_oracle(oracle):
-    """Config 3's model (two groups, its mixture variances) on a multi-tile shape."""
+@pytest.mark.parametrize("engine", [1, 2])
+def test_grouped_mixture_multi_tile_vs_oracle(oracle, engine):
+    """Config 3's model (two groups, its mixture variances) on a multi-tile shape, by both engines (the resident one: 88
+    streaming workgroups of one wave tile each)."""
     M, N = 400, 90001
     bed, y = _case(M, N, 0.0, seed=5)
     groups = (np.arange(M) % 2).astype(np.int32)
     mS = np.array([[0.0, 0.001, 0.01, 0.1]] * 2)
-    _run_vs_oracle(oracle, bed, y, N, {}, iters=3, mS=mS, groups=groups)
+    _run_vs_oracle(oracle, bed, y, N, {"engine": engine}, iters=3, mS=mS, groups=groups)
 
 
 # ---------------------------------------------------------------------------
