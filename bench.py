@@ -55,7 +55,7 @@ def algorithmic_bytes_bw(n, M, nnz, nshift):
     return M * (col + 8 * n) + nnz * 24 * n
 
 
-def committed_profile(kind, N, M, world):
+def committed_profile(kind, N, M, world, kernel="k_sweep_batch"):
     """A PMC summary committed under profiles/ (tools/profile_round.sh), newest round first, IF it was taken on this very
     workload (same N and M, one GPU); (dict, "file: command") or (None, None).  bench.py never presents such a figure
     without its source: the counters need rocprofv3 passes of their own and cannot be read inside this run."""
@@ -65,14 +65,15 @@ def committed_profile(kind, N, M, world):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("N") == N and d.get("M") == M and world == 1:
+        if d.get("N") == N and d.get("M") == M and world == 1 and d.get("kernel", "k_sweep_batch") == kernel:
             return d, "%s: %s" % (os.path.relpath(f, ROOT), d.get("command", ""))
     return None, None
 
 
 def launch_anatomy(dev, chain):
     """One more (untimed) iteration on the build of the sweep kernel that carries stage timestamps (option
-    debug_timing): where a working launch spends its time, in microseconds, averaged over that iteration."""
+    debug_timing): where a working launch (batch engine) or a round of the walker (resident engine) spends its time, in
+    microseconds, averaged over that iteration."""
     dev.set_option("debug_timing", 1)
     try:
         dev.debug_times()  # clear
@@ -81,6 +82,17 @@ def launch_anatomy(dev, chain):
         st = dev.sweep_stats()
     finally:
         dev.set_option("debug_timing", 0)
+    if st["engine"] == 2:
+        k = st["ticks"]
+        n = max(1, int(st["rounds"]))
+        us = lambda x: float(x) / 100.0 / n  # 100 MHz ticks
+        return {"engine": "resident", "period_us": st["device_ms"] * 1e3 / n, "rounds": int(st["rounds"]), "events": int(st["events"]),
+                "advances": int(st["advances"]), "walks_that_waited_for_dots": int(st["refolds"]), "shader_mhz": st["shader_mhz"],
+                "walker_us": {"wait_for_raw_dots": us(k[0]), "wait_for_gram_terms": us(k[1]), "bound_test": us(k[2]),
+                              "exact_event_and_draw": us(k[3]), "message_results_prefetch_fold": us(k[4])},
+                "streaming_workgroup0_us": {"wait_for_message": us(k[8]), "update": us(k[9]), "gram_terms": us(k[10]), "refill_dots": us(k[11]),
+                                            "barrier": us(k[12]), "raw_atomics_and_drain": us(k[13]), "count": us(k[14])},
+                "note": "build with stage clocks (a few % slower than the timed one); walker and streaming workgroup 0"}
     n = max(1, int(t[15]))
     us = lambda x: float(x) / 100.0 / n  # 100 MHz ticks
     inside = us(t[8] + t[9] + t[10] + t[11])
@@ -477,15 +489,23 @@ def main():
         bytes_alg = sum(algorithmic_bytes(n_local, M, n) for _, n in stats)
         # HIP events on the sweep's stream around each sweep / working launches: the average period of a working launch
         # (back-to-back launches: duration + the gap between dependent launches; rocprofv3's average duration agrees, profiles/)
+        engine = int(stats[-1][0].get("engine", 1))
+        resident = engine == 2
+        if resident:
+            # one launch per sweep: the kernel's launch duration IS the sweep (HIP events around it on its stream); its rounds
+            # (one per message of the walker) take the place of the batch engine's working launches in the per-launch figures
+            rounds = launches
+            launches = enqueued
         kernel_ms_avg = sweep_ms / max(1, launches)
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
-        traffic, traffic_src = committed_profile("traffic", N, M, world)
-        valu, valu_src = committed_profile("valu", N, M, world)
+        kname = "k_sweep_resident" if resident else "k_sweep_batch"
+        traffic, traffic_src = committed_profile("traffic", N, M, world, kname)
+        valu, valu_src = committed_profile("valu", N, M, world, kname)
         anatomy = anatomy_all  # measured by every rank together (below the timed region), reported by rank 0
         col_bytes = (n_local + 3) // 4
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        roof = {"bound": "latency", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic["traffic_bytes_per_launch"] if traffic else None, "traffic_source": traffic_src,
-                "kernel": "k_sweep_batch", "kernel_ms_avg": kernel_ms_avg,
+                "kernel": kname, "engine": "resident" if resident else "batch", "kernel_ms_avg": kernel_ms_avg,
                 "algorithmic_bytes_per_launch": bytes_alg / max(1, launches),
                 "sweep_ms_per_iter": sweep_ms / K,
                 # the section-8(d) byte model counts eps once per MARKER from HBM; the kernel reads it once per column group from
@@ -499,7 +519,20 @@ def main():
                 "accepted_per_launch": accepted / max(1, launches),
                 "columns_streamed_per_accepted": streamed / max(1, accepted),
                 "columns_carried_per_accepted": carried / max(1, accepted)}
-        if anatomy:
+        if resident:
+            roof["rounds_per_iter"] = rounds / K
+            roof["us_per_round"] = sweep_ms * 1e3 / max(1, rounds)
+            roof["markers_per_round"] = accepted / max(1, rounds)
+            roof["events_per_iter"] = sum(s["events"] for s, _ in stats) / K
+            roof["advances_per_iter"] = sum(s["advances"] for s, _ in stats) / K
+            roof["eps_sum_drift_max"] = max(s["eps_sum_drift"] for s, _ in stats)
+            if anatomy:
+                roof["anatomy_us"] = anatomy
+            roof["bound_statement"] = ("latency of the exact sequential chain: one round per event (message -> eps update + Gram terms on every compute unit -> "
+                                       "memory-side atomic adds -> walker), %.1f us per round, %.0f markers per round; HBM carries %.1f %% of its peak "
+                                       "(compulsory column bytes), the refill's arithmetic overlaps the walker" % (
+                                           roof["us_per_round"], roof["markers_per_round"], 100 * roof["hbm_frac_compulsory"]))
+        elif anatomy:
             loop = anatomy["entry_and_streaming_loop_us"]
             roof["anatomy_us"] = anatomy
             roof["fixed_us_per_launch"] = anatomy["period_us"] - loop
@@ -508,7 +541,8 @@ def main():
                 # the VALU instructions of a launch are issued almost entirely inside the streaming loop (the draw phase is one
                 # workgroup): issue-slot share while streaming = whole-launch share x period / loop time
                 roof["valu_frac_streaming"] = valu["valu_issue_frac"] * anatomy["period_us"] / loop
-        roof["bound_statement"] = ("latency + VALU issue: HBM carries %s of its peak; the streaming loop (%s of a launch) runs at %s of the VALU issue rate; "
+        if not resident:
+          roof["bound_statement"] = ("latency + VALU issue: HBM carries %s of its peak; the streaming loop (%s of a launch) runs at %s of the VALU issue rate; "
                                    "the rest of a launch is the serial hand-off and draw of one workgroup" % (
                                        ("%.1f %%" % (100 * roof["hbm_frac_measured"])) if roof["hbm_frac_measured"] else "%.1f %% (compulsory bytes)" % (100 * roof["hbm_frac_compulsory"]),
                                        ("%.0f %%" % (100 * roof["streaming_share_of_launch"])) if anatomy else "n/a",

@@ -32,8 +32,9 @@ f, w = work("FETCH_SIZE", "FETCH_SIZE"), work("WRITE_SIZE", "WRITE_SIZE")
 traffic = (2.0 * f["mean_work"] + w["mean_work"]) * 1024.0
 json.dump({
     "command": cmd + " (FETCH_SIZE and WRITE_SIZE in separate passes, counters only); dispatches of the timed iterations only "
-               "(the last launches_per_iter x steps dispatches of k_sweep_batch), summarised by tools/rocpd_pmc.py + tools/pmc_fold.py",
+               "(the last launches_per_iter x steps dispatches of the sweep kernel), summarised by tools/rocpd_pmc.py + tools/pmc_fold.py",
     "workload": cfg["workload"], "N": cfg["N"], "M": cfg["M"], "batch": cfg["batch"], "steps": b["steps"], "warmup": b["warmup"],
+    "kernel": b["roofline"]["kernel"],
     "dispatches_timed": f["n"], "dispatches_doing_work": f["n_work"],
     "FETCH_SIZE_KiB_mean_per_working_launch": f["mean_work"], "FETCH_SIZE_KiB_median_per_working_launch": f["median_work"],
     "WRITE_SIZE_KiB_mean_per_working_launch": w["mean_work"],
@@ -58,6 +59,7 @@ gui = s1["GRBM_GUI_ACTIVE"]["mean_work"] / XCDS
 cap = gui / 4.0 * 1024.0
 json.dump({
     "command": cmd + " (two SQ passes)", "workload": b1["config"]["workload"], "N": b1["config"]["N"], "M": b1["config"]["M"],
+    "kernel": b1["roofline"]["kernel"],
     "steps": b1["steps"], "warmup": b1["warmup"], "dispatches_timed": s1["SQ_INSTS_VALU"]["n"],
     "per_working_launch_mean": {k: v["mean_work"] for k, v in {**s1, **{k: v for k, v in s2.items() if k != "GRBM_GUI_ACTIVE"}}.items()},
     "GRBM_GUI_ACTIVE_second_pass": s2["GRBM_GUI_ACTIVE"]["mean_work"], "gui_active_cycles_per_xcd": gui,

@@ -4,7 +4,7 @@
 #   2. the kernel trace of the same command (rocprofv3 --kernel-trace --stats), summarised over the timed iterations;
 #   3. PMC passes over the same command, counters only, one group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass;
 #      SQ and GRBM counters in two more), each summarised over the dispatches of the TIMED iterations (the last
-#      launches_per_iter * steps dispatches of k_sweep_batch), and folded into <R>_c4_pmc_traffic.json / <R>_c4_pmc_valu.json,
+#      launches_per_iter * steps dispatches of the sweep kernel: k_sweep_resident, one per sweep, or k_sweep_batch), and folded into <R>_c4_pmc_traffic.json / <R>_c4_pmc_valu.json,
 #      which bench.py quotes with their source.
 # usage (on the GPU box, repo root): bash tools/profile_round.sh rNN [steps] [warmup]
 set -e
@@ -20,7 +20,8 @@ echo "bench done"; cut -c1-400 $O/${R}_c4_bench.json
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-anatomy > $O/${R}_c4_bench_under_rocprof.json 2> $O/kt.err
 DB=$(ls $O/kt/*results.db $O/kt/*/*results.db 2>/dev/null | head -1)
 L=$(python3 -c "import json; d=json.load(open('$O/${R}_c4_bench_under_rocprof.json')); print(int(round(d['config']['launches_per_iter']*d['steps'])))")
-python3 tools/rocpd_stats.py $DB $O/${R}_c4_kernel_stats.csv k_sweep_batch $L > $O/${R}_c4_kernel_timed_region.txt
+KERN=$(python3 -c "import json; d=json.load(open('$O/${R}_c4_bench_under_rocprof.json')); print(d['roofline']['kernel'])")
+python3 tools/rocpd_stats.py $DB $O/${R}_c4_kernel_stats.csv $KERN $L > $O/${R}_c4_kernel_timed_region.txt
 cat $O/${R}_c4_kernel_timed_region.txt
 rm -rf $O/kt
 echo "kernel trace done"
@@ -30,7 +31,8 @@ pmc_pass () { # name, counters...
   rocprofv3 --pmc "$@" -d $O/pmc_$NAME -o p -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-anatomy > $O/pmc_$NAME.json 2> $O/pmc_$NAME.err
   local DBP=$(ls $O/pmc_$NAME/*results.db $O/pmc_$NAME/*/*results.db 2>/dev/null | head -1)
   local LP=$(python3 -c "import json; d=json.load(open('$O/pmc_$NAME.json')); print(int(round(d['config']['launches_per_iter']*d['steps'])))")
-  python3 tools/rocpd_pmc.py $DBP k_sweep_batch $LP > $O/${R}_c4_pmc_$NAME.txt
+  local KP=$(python3 -c "import json; d=json.load(open('$O/pmc_$NAME.json')); print(d['roofline']['kernel'])")
+  python3 tools/rocpd_pmc.py $DBP $KP $LP > $O/${R}_c4_pmc_$NAME.txt
   cat $O/${R}_c4_pmc_$NAME.txt | cut -c1-300
   rm -rf $O/pmc_$NAME
   echo "pmc pass $NAME done"
