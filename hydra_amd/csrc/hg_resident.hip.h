@@ -35,13 +35,16 @@ constexpr int RS_RSH = 8;                 // shards of the raw-dot accumulators 
 constexpr int RS_GROW = 1024;             // u32 words from one Gram accumulator row to the next (4 KiB: rows on different channels)
 constexpr int RS_CROW = 1024;             // the same for the batch counters
 constexpr int RS_RB = 2 * RS_BMAX;        // raw-dot accumulators: positions mod RS_RB
-constexpr int RS_MSG = 4;                 // message slots (seq mod RS_MSG)
+constexpr int RS_MSG = 16;                // message slots (seq mod RS_MSG): the walker is never more than RS_MSG - 2 messages ahead of the slowest workgroup
+constexpr int RS_PMAX = 4;                // predicted pivots per refill batch whose Gram terms are taken when a column is streamed
+constexpr int RS_PFIRE = 16;              // fired pivots whose corrections some not yet arrived column still needs
+constexpr int RS_NB = 256;                // refill batches the walker keeps the pivot lists of (a batch holds at least one position of the window)
 constexpr int RS_TRACE = 4096;            // messages whose stamps the debug build keeps
 constexpr int RS_TMAX = 2;                // most wave tiles per workgroup (16 T doubles of eps per lane, in every wave; a build for 4 spills registers)
 constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
 
-enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_LAST = 8 }; // message kinds; RS_LAST is a flag bit
+enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has); RS_LAST is a flag bit
 
 // tag = seq << 32 | kind << 28 | ncons: the walker consumed `ncons` positions; RS_EVENT: the last of them changed its
 // effect by -dbeta (dbeta = old - new)
@@ -52,7 +55,7 @@ struct ResMsg {
 
 struct ResState { // device -> host, written by the walker at the end of the sweep
     uint32_t cursor, rng_idx, error, pad;
-    unsigned long long rounds, events, advances, nnz, chunks, refolds;
+    unsigned long long rounds, events, advances, nnz, chunks, refolds, pivots;
     unsigned long long shader_ticks, wall_ticks; // s_memtime and 100 MHz wall clock over the walker's life: the clock the chip held
     unsigned long long t[16]; // 100 MHz ticks: walker [0] fold [1] collect [2] evaluate [3] scan + draw [4] announce + outputs + prefetch;
                               // streaming workgroup 0: [8] poll [9] update [10] Gram [11] refill dots [12] barrier [13] raw atomics + drain [14] barrier + count [15] prefetch issue
@@ -88,6 +91,7 @@ struct ResParams {
     uint32_t* gacc;           // [2][RS_NSH] rows of RS_GROW words, RS_BMAX in use: count << 24 | sum of the workgroups' Gram terms
     unsigned long long* racc; // [RS_RSH][RS_RB]: sum of the workgroups' raw dots (51-bit fixed point) of position p at p mod RS_RB
     uint32_t* rcnt;           // [RS_RSH] words RS_CROW apart: refill batches the shard's workgroups have completed
+    uint32_t* pacc;           // [RS_RSH][RS_PMAX][RS_RB]: sum of the workgroups' Gram terms of position p (at p mod RS_RB) with its batch's pivots
     ResMsg* msg;              // [RS_MSG]
     ResState* state;
     double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale), |.| < 2^51 per workgroup
@@ -96,6 +100,7 @@ struct ResParams {
                                   // reports when its deadline passes (a store to host memory here would put a PCIe round trip in front of the next barrier)
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
+    int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
 };
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -128,7 +133,7 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
     return v;
 }
 
-__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 80 + (size_t)B * 256 * T; }
+__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 97 + (size_t)B * 256 * T; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
@@ -188,17 +193,25 @@ __device__ __forceinline__ void rs_set_read(uint32_t (&w)[T], const uint32_t (&k
 }
 
 // per-lane values that travel with the sets (their loads must not make the compiler wait either): lane r keeps (mave, mstd) of set r's
-// column in v[216:217], v[218:219] and the marker id of the set's NEXT column in v220 -- named registers as well
-__device__ __forceinline__ void rs_lane_load(const double* mave, const double* mstd, const int32_t* id)
+// column in v[216:217], v[218:219], its effect at sweep start in v[222:223] and the marker id of the set's NEXT column in v220 -- named registers as well
+__device__ __forceinline__ void rs_lane_load(const double* mave, const double* mstd, const double* bold, const int32_t* id)
 {
-    asm volatile("global_load_dwordx2 v[216:217], %0, off\n\tglobal_load_dwordx2 v[218:219], %1, off\n\tglobal_load_dword v220, %2, off" ::"v"(mave), "v"(mstd), "v"(id)
-                 : "memory", "v216", "v217", "v218", "v219", "v220");
+    asm volatile("global_load_dwordx2 v[216:217], %0, off\n\tglobal_load_dwordx2 v[218:219], %1, off\n\tglobal_load_dwordx2 v[222:223], %2, off\n\tglobal_load_dword v220, %3, off" ::"v"(mave),
+                 "v"(mstd), "v"(bold), "v"(id)
+                 : "memory", "v216", "v217", "v218", "v219", "v220", "v222", "v223");
 }
 __device__ __forceinline__ double2 rs_lane_meta()
 {
     int a0, a1, b0, b1;
     asm volatile("v_mov_b32 %0, v216\n\tv_mov_b32 %1, v217\n\tv_mov_b32 %2, v218\n\tv_mov_b32 %3, v219" : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1));
     return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
+}
+// the column's effect at sweep start (non-zero: a predicted pivot)
+__device__ __forceinline__ double rs_lane_bold()
+{
+    int a0, a1;
+    asm volatile("v_mov_b32 %0, v222\n\tv_mov_b32 %1, v223" : "=&v"(a0), "=&v"(a1));
+    return __hiloint2double(a1, a0);
 }
 // the lanes' next ids as an ordinary value (read behind the wait; the compiler then takes care of the readlane hazards itself)
 __device__ __forceinline__ int32_t rs_lane_ids()
@@ -220,7 +233,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
     double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
     double* const part = reinterpret_cast<double*>(smem + 512 + (size_t)B * 16);       // this round's refill: [position - Sx][8] sums of the wave's eight-lane groups
-    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 80);  // [B][64 * T] codes of the window columns
+    uint8_t* const pflag = smem + 512 + (size_t)B * 80;                                // window slot: the column is a predicted pivot (effect non-zero at sweep start)
+    uint32_t* const pterm = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 81);  // this round's refill: [position - Sx][RS_PMAX] Gram terms with the batch's pivots
+    uint32_t* const pivl = reinterpret_cast<uint32_t*>(smem + 320);                    // [0] = number of the batch's pivots, [1 ..] their positions
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 97);  // [B][64 * T] codes of the window columns
     const bool timing = DBG && wg == 0 && tid == 0;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
@@ -269,7 +285,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         rs_set_load<T, r>(voff, p.bed + (size_t)(pn < M ? mk : 0) * p.stride);
     };
     // lane r < RS_PF: (mave, mstd) of the column of position p1 and the id of position p2
-    auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u)); };
+    auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.s_bold + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u)); };
     {
         // sets 0 .. RS_PF - 1 for k = 0 .. RS_PF - 1: the ids first (ordinary load), then the columns, then the lanes' values
         const uint32_t mp = pos_of((uint32_t)lane);
@@ -279,7 +295,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         if (lane < RS_PF) lane_load(mp, pos_of((uint32_t)lane + RS_PF));
     }
     for (;;) {
-        const bool upd = kind == RS_EVENT;
+        const bool upd = kind == RS_EVENT || kind == RS_PIVOT; // RS_PIVOT: the walker has this event's Gram terms already
+        const bool with_gram = kind == RS_EVENT;
         if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
         const uint32_t Cn = C + ncons;
@@ -311,7 +328,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
             const uint32_t V = Sx - (q + 1u);
             const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
-            if (V) {
+            if (V && with_gram) {
             GramPivot gp[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) gp[t] = gram_pivot(xq[t]);
@@ -350,12 +367,13 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words: count in the top byte
                 __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
             }
-            ++nev;
+            if (with_gram) ++nev;
             lap(2);
             if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
+        const uint32_t round_k0 = nk; // this wave's columns of the round: k in [round_k0, nk) behind the passes
         uint32_t done_k0 = nk, done_m = 0; // the sets the last pass consumed: reloaded behind the raw dots
         while (count_w) {
             if (done_m) cols_landed(); // a second pass in one round (more than 8 RS_PF new columns): its columns are asked for here and now
@@ -416,6 +434,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));
                 if (lane < RS_PF && kl - nk < m) {
                     meta[pos_of(kl) & bmask] = rs_lane_meta();
+                    pflag[pos_of(kl) & bmask] = (uint8_t)(rs_lane_bold() != 0.0 ? 1 : 0);
                     lane_load(pos_of(kl + (uint32_t)RS_PF), pos_of(kl + 2u * (uint32_t)RS_PF));
                 }
             }
@@ -428,6 +447,48 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the window's new columns and this round's group sums are in LDS for every wave
         lap(4);
         if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
+        // ---- Gram terms with the batch's pivots.  A marker whose effect is non-zero at sweep start WILL change (a predicted event):
+        // the first RS_PMAX of them in the window as it stands now, [Cn, Sn), are this batch's pivots, and every column of the batch
+        // behind one of them takes its integer Gram term with it here, where both columns are in LDS -- the walker then needs no
+        // round trip when that pivot's turn comes (message RS_PIVOT).  Wave 0 finds the pivots, in position order.
+        if (tid < WAVE) {
+            uint32_t np = 0;
+            for (uint32_t b0 = Cn; p.pivots && b0 < Sn && np < (uint32_t)RS_PMAX; b0 += WAVE) {
+                const uint32_t pp = b0 + (uint32_t)lane;
+                unsigned long long m = __ballot(pp < Sn && pflag[pp & bmask] != 0);
+                while (m && np < (uint32_t)RS_PMAX) {
+                    const uint32_t b = (uint32_t)(__ffsll((long long)m) - 1);
+                    if (lane == 0) pivl[1 + np] = b0 + b;
+                    ++np;
+                    m &= m - 1ull;
+                }
+            }
+            if (lane == 0) pivl[0] = np;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const uint32_t np = pivl[0];
+            for (uint32_t ip = 0; ip < np; ++ip) { // wave-uniform loops
+                const uint32_t pv = pivl[1 + ip];
+                GramPivot gq[T];
+                {
+                    const uint32_t* rp = ring + (pv & bmask) * 64u * T + (uint32_t)lane * T;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) gq[t] = gram_pivot(rp[t]);
+                }
+                for (uint32_t k = round_k0; k < nk; ++k) {
+                    const uint32_t pos = pos_of(k);
+                    if (pos <= pv) continue;
+                    const uint32_t* rp = ring + (pos & bmask) * 64u * T + (uint32_t)lane * T;
+                    uint32_t g = 0u;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) g += gram16x(gram_xform(rp[t]), gq[t]);
+                    const uint32_t tot = wave_sum_u32(g);
+                    if (lane == 0) pterm[(pos - Sx) * (uint32_t)RS_PMAX + ip] = tot;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // One thread per refilled position adds the eight group sums of its column in order and sends the workgroup's part of s1 as
         // a 51-bit fixed-point integer -- taken from "x + 1.5 2^52" (round to nearest, exact for |x| < 2^51) -- by an 8-byte atomic add
         // (contiguous over the threads: one 64-byte request per eight positions): sums over workgroups are exact and do not depend on
@@ -443,6 +504,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             const double MAGIC = 6755399441055744.0;
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
+            const uint32_t np = pivl[0];
+            for (uint32_t ip = 0; ip < np; ++ip)
+                if (pivl[1 + ip] < Sx + t)
+                    __hip_atomic_fetch_add(p.pacc + ((size_t)(wg % p.rsh) * RS_PMAX + ip) * RS_RB + ((Sx + t) % RS_RB), pterm[t * (uint32_t)RS_PMAX + ip], HG_RLX_AGENT);
         }
         wait_vmcnt<0>();
         lap(5);
@@ -515,6 +580,15 @@ struct WalkShared {
     double* tq;     // [MT_BUF] per word of the staged generator blocks: the largest max_l (logL_l - logL_0) that cannot give an event
     double* qtab;   // [2][HT_LDS]: per (group, component) c = logpi - hlog - logpi_0 and r = 1 / (2 sigmaE denom)
     uint16_t* crank; // [RS_BMAX] rank of the window position among the markers that take a uniform (adaV), this walk
+    uint32_t* bl_pos; // [RS_NB][RS_PMAX] the pivots of a refill batch (positions, in order), by batch number mod RS_NB
+    uint8_t* bl_np;   // [RS_NB] how many
+    uint32_t* w_pt;   // [B][RS_PMAX] window slot: its column's Gram terms with its batch's pivots (those in front of it)
+    uint32_t* pprev;  // [RS_PMAX][RS_RB] sum over the shards of the pivot-term words as last seen
+    uint32_t* pf_pos; // [RS_PFIRE] pivots that fired while columns streamed before their update were still without their dot:
+    uint32_t* pf_msg; //            position, message number, then (dbeta, mave, mstd)
+    double* pf_val;   // [RS_PFIRE][3]
+    double* ebn;      // [B] window slot: the new effect of an event decided there (results are written behind the message)
+    uint8_t* ekq;     // [B] its component
     uint8_t* ada;
     uint8_t* fdone; // the slot's raw dot has arrived
     unsigned char* end;
@@ -524,7 +598,7 @@ struct WalkShared {
     uint32_t* fl;   // 64 words of flags
     int32_t* lcass; // [256]
 };
-enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7, WF_CAND = 8, WF_NADA = 9 };
+enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7, WF_CAND = 8, WF_NADA = 9, WF_COVER = 10 };
 enum { WD_DBETA = 0, WD_BNEW = 1, WD_PROB = 2 };
 
 __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
@@ -543,6 +617,8 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.num = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.ebuf = reinterpret_cast<double*>(q); q += (size_t)RS_BLOCK * 8;
     s.rprev = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
+    s.pf_val = reinterpret_cast<double*>(q); q += (size_t)RS_PFIRE * 3 * 8;
+    s.ebn = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.tq = reinterpret_cast<double*>(q); q += (size_t)MT_BUF * 8;
     s.qtab = reinterpret_cast<double*>(q); q += (size_t)2 * HT_LDS * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
@@ -552,7 +628,14 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.gpart = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_NSH * RS_BMAX * 4;
     s.fl = reinterpret_cast<uint32_t*>(q); q += 64 * 4;
     s.lcass = reinterpret_cast<int32_t*>(q); q += 256 * 4;
+    s.bl_pos = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_NB * RS_PMAX * 4;
+    s.w_pt = reinterpret_cast<uint32_t*>(q); q += (size_t)B * RS_PMAX * 4;
+    s.pprev = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PMAX * RS_RB * 4;
+    s.pf_pos = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PFIRE * 4;
+    s.pf_msg = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PFIRE * 4;
     s.crank = reinterpret_cast<uint16_t*>(q); q += (size_t)RS_BMAX * 2;
+    s.bl_np = q; q += RS_NB;
+    s.ekq = q; q += B;
     s.bigf = q; q += RS_BLOCK;
     s.ada = q; q += B;
     s.fdone = q; q += B;
@@ -606,6 +689,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.qtab[HT_LDS + i] = (i % K) ? p.i_2sigE / p.denom[i] : 0.0;
         }
     for (int i = tid; i < RS_RB; i += RS_BLOCK) sh.rprev[i] = 0ull;
+    for (int i = tid; i < RS_PMAX * RS_RB; i += RS_BLOCK) sh.pprev[i] = 0u;
     if (tid < 64) sh.fl[tid] = 0u;
     auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
         if (lds_tab) return sh.htab[which * HT_LDS + t];
@@ -639,10 +723,30 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     bool pendG = false;
     uint32_t gq = 0, gV = 0;          // the event whose Gram terms are still to be collected: position, window columns behind it
     double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0;
-    unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0;
+    unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0;
+    // the pivots of refill batch `batch`: the first RS_PMAX positions of the window [lo, hi) -- as it stands when the batch is streamed --
+    // whose marker has a non-zero effect at sweep start (the streaming workgroups find the same list: res_streamer)
+    auto batch_pivots = [&](uint32_t batch, uint32_t lo, uint32_t hi) {
+        if (tid < WAVE) {
+            uint32_t np = 0;
+            for (uint32_t b0 = lo; p.pivots && b0 < hi && np < (uint32_t)RS_PMAX; b0 += WAVE) {
+                const uint32_t pp = b0 + (uint32_t)lane;
+                unsigned long long m = __ballot(pp < hi && sh.bold[pp & bmask] != 0.0);
+                while (m && np < (uint32_t)RS_PMAX) {
+                    const uint32_t b = (uint32_t)(__ffsll((long long)m) - 1);
+                    if (lane == 0) sh.bl_pos[(batch % RS_NB) * RS_PMAX + np] = b0 + b;
+                    ++np;
+                    m &= m - 1ull;
+                }
+            }
+            if (lane == 0) sh.bl_np[batch % RS_NB] = (uint8_t)np;
+        }
+    };
+    uint32_t pf_n = 0; // fired pivots on record (sh.pf_*)
     prefetch(0u, Sx, 0u);
     __syncthreads();
     stage_tq(0, MT_N);
+    batch_pivots(0u, 0u, Sx);
     __syncthreads();
 
     // Refill batches all workgroups have completed (their raw dots are summed in racc): wave 0 reads the shards' counters.
@@ -679,6 +783,27 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         sh.rprev[j % RS_RB] = now;
         const double s1 = (double)(long long)tot * p.fx_unscale;
         sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
+        // the column's Gram terms with its batch's pivots (those in front of it), and the corrections of the pivots that have fired since
+        // the column was streamed
+        const uint32_t bt = sh.batch[slot], np = sh.bl_np[bt % RS_NB];
+        const uint32_t* bp = sh.bl_pos + (bt % RS_NB) * RS_PMAX;
+        for (uint32_t ip = 0; ip < np; ++ip) {
+            if (bp[ip] >= j) break;
+            uint32_t nowp = 0u;
+            for (uint32_t sidx = 0; sidx < p.rsh; ++sidx) nowp += __hip_atomic_load(p.pacc + ((size_t)sidx * RS_PMAX + ip) * RS_RB + (j % RS_RB), HG_RLX_AGENT);
+            sh.w_pt[slot * RS_PMAX + ip] = nowp - sh.pprev[ip * RS_RB + (j % RS_RB)];
+            sh.pprev[ip * RS_RB + (j % RS_RB)] = nowp;
+        }
+        for (uint32_t f = 0; f < pf_n; ++f) {
+            const uint32_t fq = sh.pf_pos[f];
+            if (sh.pf_msg[f] > bt && fq < j) {
+                for (uint32_t ip = 0; ip < np; ++ip)
+                    if (bp[ip] == fq) {
+                        const double xx = sh.mstd[slot] * sh.pf_val[3 * f + 2] * ((double)sh.w_pt[slot * RS_PMAX + ip] - p.n_total * (sh.mave[slot] * sh.pf_val[3 * f + 1]));
+                        sh.dp[slot] += sh.pf_val[3 * f] * xx;
+                    }
+            }
+        }
         sh.fdone[slot] = 1;
     };
     // one pass over the positions [F, Sx) that have no dot yet; afterwards F = the first one still missing
@@ -939,6 +1064,44 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         const bool is_event = found && dbeta != 0.0;
         const uint32_t Cn = C + ncons;
         const bool lastmsg = Cn >= M;
+        // A predicted pivot whose Gram terms came with the columns: every refill batch that has columns behind it in the window must
+        // list it (wave 0 checks the batches, one per lane).  Then nobody has to be waited for: message RS_PIVOT, corrections now.
+        bool pivot = false;
+        if (p.pivots && is_event && sh.bold[qpos & bmask] != 0.0 && pf_n < (uint32_t)RS_PFIRE) { // uniform
+            if (tid < WAVE) {
+                bool ok = true;
+                if (qpos + 1u < Sx) {
+                    const uint32_t b_lo = sh.batch[(qpos + 1u) & bmask], nb = seq - b_lo + 1u; // batches b_lo .. seq have columns behind q
+                    ok = nb <= (uint32_t)WAVE;
+                    bool mine = true;
+                    if ((uint32_t)lane < nb && ok) {
+                        const uint32_t b = b_lo + (uint32_t)lane;
+                        mine = false;
+                        for (uint32_t ip = 0; ip < sh.bl_np[b % RS_NB]; ++ip) mine = mine || sh.bl_pos[(b % RS_NB) * RS_PMAX + ip] == qpos;
+                    }
+                    ok = ok && __ballot(!mine) == 0ull;
+                }
+                if (lane == 0) sh.fl[WF_COVER] = ok ? 1u : 0u;
+            }
+            __syncthreads();
+            pivot = sh.fl[WF_COVER] != 0u;
+        }
+        // the walker is never more than RS_MSG - 3 messages ahead of the slowest streaming workgroup (messages without a Gram round trip
+        // would otherwise let it run away): batches completed = messages taken + 1
+        if (seq + 3u > sh.fl[WF_RDONE] + (uint32_t)RS_MSG - 3u) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                __syncthreads();
+                if (tid == 0 && wall_clock64() - t0 > p.timeout) sh.fl[WF_ABORT] = 1u;
+                refresh_batches();
+                __syncthreads();
+                if (seq + 3u <= sh.fl[WF_RDONE] + (uint32_t)RS_MSG - 3u || sh.fl[WF_ABORT]) break;
+            }
+            if (sh.fl[WF_ABORT]) {
+                aborted = true;
+                break;
+            }
+        }
         __syncthreads();
         ++seq;
         if (DBG && tid == 0) {
@@ -947,11 +1110,37 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             p.trace[0 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
         if (tid == 0) {
-            const uint32_t kf = (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE) | (lastmsg ? (uint32_t)RS_LAST : 0u);
+            const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE)) | (lastmsg ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
             rs_store16(p.msg + (seq % RS_MSG), rs_u4((kf << 28) | ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)));
         }
-        if (is_event) {
+        if (pivot) {
+            // corrections of the window columns behind q that have their dot; the others get theirs when it arrives (try_raw)
+            const uint32_t qs = qpos & bmask;
+            const double mq = sh.mave[qs], sq = sh.mstd[qs];
+            for (uint32_t j = qpos + 1u + (uint32_t)tid; j < F; j += RS_BLOCK) {
+                const uint32_t slot = j & bmask, bt = sh.batch[slot];
+                const uint32_t* bp = sh.bl_pos + (bt % RS_NB) * RS_PMAX;
+                for (uint32_t ip = 0; ip < sh.bl_np[bt % RS_NB]; ++ip)
+                    if (bp[ip] == qpos) {
+                        const double xx = sh.mstd[slot] * sq * ((double)sh.w_pt[slot * RS_PMAX + ip] - p.n_total * (sh.mave[slot] * mq));
+                        sh.dp[slot] += dbeta * xx;
+                    }
+            }
+            if (F < Sx) { // columns behind q whose dot (streamed before this update) is still on its way
+                if (tid == 0) {
+                    sh.pf_pos[pf_n] = qpos;
+                    sh.pf_msg[pf_n] = seq;
+                    sh.pf_val[3 * pf_n] = dbeta;
+                    sh.pf_val[3 * pf_n + 1] = mq;
+                    sh.pf_val[3 * pf_n + 2] = sq;
+                }
+                ++pf_n;
+            }
+            ++n_pivots;
+            ++n_events;
+            ++n_nnz;
+        } else if (is_event) {
             const uint32_t slot = qpos & bmask;
             pendG = true;
             gq = qpos;
@@ -1035,10 +1224,38 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             has_next = false;
         }
         __syncthreads();
+        batch_pivots(seq, Cn, Sn);
         Sx = Sn;
         C = Cn;
         if (tid == 0) p.progress[0] = (n_rounds << 8) | 6u;
         fold_pass(); // dots of the refills that have arrived meanwhile (off the chain: the streaming workgroups are busy with the message)
+        // fired pivots are on record only while a column streamed before their update is still without its dot: positions in front of
+        // F all have theirs, and the batches behind are in position order
+        if (F >= Sx) {
+            pf_n = 0;
+        } else {
+            const uint32_t bF = sh.batch[F & bmask];
+            uint32_t keep = 0;
+            for (uint32_t f = 0; f < pf_n; ++f) keep += sh.pf_msg[f] > bF ? 1u : 0u;
+            if (keep == 0u) pf_n = 0; // (entries are in message order: either a tail survives or nothing -- a partial prune compacts below)
+            else if (keep < pf_n) {
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t w = 0;
+                    for (uint32_t f = 0; f < pf_n; ++f)
+                        if (sh.pf_msg[f] > bF) {
+                            sh.pf_pos[w] = sh.pf_pos[f];
+                            sh.pf_msg[w] = sh.pf_msg[f];
+                            sh.pf_val[3 * w] = sh.pf_val[3 * f];
+                            sh.pf_val[3 * w + 1] = sh.pf_val[3 * f + 1];
+                            sh.pf_val[3 * w + 2] = sh.pf_val[3 * f + 2];
+                            ++w;
+                        }
+                }
+                pf_n = keep;
+                __syncthreads();
+            }
+        }
         lap(4);
     }
 
@@ -1062,6 +1279,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         st->nnz = n_nnz;
         st->chunks = n_chunks;
         st->refolds = n_refold;
+        st->pivots = n_pivots;
         st->shader_ticks = __builtin_amdgcn_s_memtime() - clk0;
         st->wall_ticks = wall_clock64() - wall0;
         if (DBG)

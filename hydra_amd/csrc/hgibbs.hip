@@ -149,6 +149,7 @@ struct hgibbs_ctx {
     bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
+    int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
     ResMsg* res_msg = nullptr;
     ResState* res_state = nullptr;
@@ -172,8 +173,8 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
     return 0;
 }
 
-static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4;
-static constexpr size_t RES_ACC_BYTES = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES;
+static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4, RES_PACC_BYTES = (size_t)RS_RSH * RS_PMAX * RS_RB * 4;
+static constexpr size_t RES_ACC_BYTES = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES + RES_PACC_BYTES;
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
 static constexpr size_t MBOX_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long);
 
@@ -1139,6 +1140,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "window")) {
         if (value != 0 && (value < 8 || value > RS_BMAX || (value & (value - 1)))) return fail("window must be 0 (auto) or a power of two in [8,%d]", RS_BMAX);
         h->window = (uint32_t)value;
+    } else if (!std::strcmp(name, "pivots")) {
+        h->res_pivots = value != 0;
     } else if (!std::strcmp(name, "res_cus")) {
         if (value < 0 || value > 4096) return fail("res_cus must be in [0,4096]");
         h->res_cus = (uint32_t)value;
@@ -1285,6 +1288,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.gacc = reinterpret_cast<uint32_t*>(h->res_acc);
     p.racc = reinterpret_cast<unsigned long long*>(h->res_acc + RES_GACC_BYTES);
     p.rcnt = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES);
+    p.pacc = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES);
     p.msg = h->res_msg;
     p.state = h->res_state;
     {
@@ -1301,6 +1305,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     }
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.dbg = h->debug_timing ? 1 : 0;
+    p.pivots = h->res_pivots;
     p.trace = h->res_trace;
     p.progress = h->res_progress;
     HIP_TRY(hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream));
@@ -1383,6 +1388,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.advances = st.advances;
     s.chunks = st.chunks;
     s.refolds = st.refolds;
+    s.pivots = st.pivots;
     for (int i = 0; i < 16; ++i) s.ticks[i] = st.t[i];
     s.shader_mhz = st.wall_ticks ? 100.0 * (double)st.shader_ticks / (double)st.wall_ticks : 0.0;
     {
@@ -1684,7 +1690,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     h->stats.tiles_per_workgroup_max = cnt_host->tiles_max;
     h->stats.kernel_ms_avg = cnt_host->launches ? ms / (double)cnt_host->launches : 0.0;
     h->stats.engine = 1;
-    h->stats.rounds = h->stats.events = h->stats.advances = h->stats.chunks = h->stats.refolds = 0;
+    h->stats.rounds = h->stats.events = h->stats.advances = h->stats.chunks = h->stats.refolds = h->stats.pivots = 0;
     h->stats.shader_mhz = 0.0;
     for (int i = 0; i < 16; ++i) h->stats.ticks[i] = 0;
     {

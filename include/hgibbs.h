@@ -178,6 +178,7 @@ typedef struct {
     /* resident engine: rounds of the walker (= working_launches), events (messages that carried an update), rounds that only
      * advanced the window, posterior chunks evaluated, chunks that had to wait for dots streamed behind the last message */
     uint64_t rounds, events, advances, chunks, refolds;
+    uint64_t pivots;          /* resident engine: events that needed no round trip (predicted pivots whose Gram terms came with the columns) */
     double shader_mhz;        /* resident engine: s_memtime ticks per microsecond over the sweep (the clock the walker's compute unit held) */
     uint64_t ticks[16];       /* resident engine with option debug_timing: 100 MHz ticks, walker [0] fold [1] collect [2] evaluate
                                * [3] scan + draw [4] message + results + prefetch; streaming workgroup 0: [8] wait [9] update [10] Gram [11] stream */

@@ -143,6 +143,19 @@ def test_geometry_does_not_change_the_chain(oracle):
         assert close(o[0], outs[0][0], 1e-10) and close(o[2], outs[0][2], 1e-10)
 
 
+@pytest.mark.parametrize("window", [16, 64, 256])
+def test_predicted_pivots(oracle, window):
+    """Option pivots: the Gram terms of the markers whose effect is non-zero at sweep start come with the streamed columns, and their
+    events need no round trip (messages RS_PIVOT, corrections from the stored terms, also for columns whose dot arrives later)."""
+    ch, ref, dev = run_vs_oracle(oracle, 500, 5000, iters=5, opts={"window": window, "pivots": 1}, causal_frac=0.2)
+    assert dev.sweep_stats()["pivots"] > 0
+
+
+def test_predicted_pivots_many_workgroups(oracle):
+    ch, ref, dev = run_vs_oracle(oracle, 600, 20011, iters=4, opts={"pivots": 1}, causal_frac=0.1)
+    assert dev.sweep_stats()["pivots"] > 0
+
+
 def test_refused_where_it_does_not_apply(oracle):
     geno = synth.make_genotypes(50, 500, seed=1, missing_rate=0.05)
     y, _ = synth.make_phenotype(geno, seed=2)

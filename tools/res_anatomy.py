@@ -31,8 +31,8 @@ for it in range(iters):
     ch.iterate()
     dt = time.perf_counter() - t0
     s = dev.sweep_stats()
-    print("[%.0f MHz] it %d: %.1f ms wall, %.1f ms device, %d rounds (%d events, %d advances), %.2f us/round, %d chunks, %d refolds, %.3f M markers/s, drift %.2e"
-          % (s["shader_mhz"], it, dt * 1e3, s["device_ms"], s["rounds"], s["events"], s["advances"], s["device_ms"] * 1e3 / max(1, s["rounds"]),
+    print("[%.0f MHz] it %d: %.1f ms wall, %.1f ms device, %d rounds (%d events of which %d pivots, %d advances), %.2f us/round, %d chunks, %d refolds, %.3f M markers/s, drift %.2e"
+          % (s["shader_mhz"], it, dt * 1e3, s["device_ms"], s["rounds"], s["events"], s["pivots"], s["advances"], s["device_ms"] * 1e3 / max(1, s["rounds"]),
              s["chunks"], s["refolds"], M / dt / 1e6, s["eps_sum_drift"]))
 t = s["ticks"]
 n = max(1, s["rounds"])
