@@ -70,13 +70,27 @@ def committed_profile(kind, N, M, world, kernel="k_sweep_batch"):
     return None, None
 
 
-def launch_anatomy(dev, chain):
+def launch_anatomy(dev, chain, dist=None):
     """One more (untimed) iteration on the build of the sweep kernel that carries stage timestamps (option
     debug_timing): where a working launch (batch engine) or a round of the walker (resident engine) spends its time, in
-    microseconds, averaged over that iteration."""
-    dev.set_option("debug_timing", 1)
+    microseconds, averaged over that iteration.  With several ranks the iteration is collective: the ranks first agree
+    (a MIN over a flag) that every one of them switched builds, and none enters the iteration unless all did."""
+    ok = 1
     try:
+        dev.set_option("debug_timing", 1)
         dev.debug_times()  # clear
+    except Exception as e:
+        print("launch anatomy: this rank could not switch builds: %r" % (e,), file=sys.stderr)
+        ok = 0
+    if dist is not None:
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag[0])
+    if not ok:
+        dev.set_option("debug_timing", 0)
+        raise RuntimeError("a rank could not switch to the build with stage clocks; anatomy skipped on every rank")
+    try:
         chain.iterate()
         t = dev.debug_times()
         st = dev.sweep_stats()
@@ -122,6 +136,9 @@ def make_phenotype_on_device(dev, n_global, M, rank_rows, seed, h2=0.5, causal_f
     return dev.get_residual()
 
 
+BULK = None  # transport of the bulk reductions, agreed on by all ranks at the first handle: "rccl" or "gloo"
+
+
 def make_multirank_device(capi, dist, world, rank, local_rank, want_p2p):
     """One handle per rank: a communicator for the rare bulk reductions (RCCL; or
     gloo through the external hook when HGIBBS_BENCH_BULK=gloo, which is how two
@@ -130,16 +147,42 @@ def make_multirank_device(capi, dist, world, rank, local_rank, want_p2p):
     Every collective below is executed by every rank whatever fails locally.
     Returns (device, p2p_enabled)."""
     import torch
+
+    def allreduce(arr):
+        t = torch.from_numpy(arr.view(np.int64) if arr.dtype == np.uint64 else arr)
+        dist.all_reduce(t)
+
+    global BULK
     dev = capi.Device(local_rank)
-    if os.environ.get("HGIBBS_BENCH_BULK", "rccl") == "gloo":
-        def allreduce(arr):
-            t = torch.from_numpy(arr.view(np.int64) if arr.dtype == np.uint64 else arr)
-            dist.all_reduce(t)
-        dev.comm_init_external(world, rank, allreduce)
-    else:
-        uid = [capi.Device.unique_id() if rank == 0 else None]
+    if BULK is None:
+        BULK = os.environ.get("HGIBBS_BENCH_BULK", "rccl")
+    if BULK == "rccl":
+        # RCCL for the bulk reductions; if ANY rank cannot join the communicator, every rank falls back to gloo together
+        # (and stays there for the rest of the run: the ranks must not disagree on the transport)
+        ok, uid = 1, [None]
+        try:
+            if rank == 0:
+                uid = [capi.Device.unique_id()]
+        except Exception as e:
+            print("rank 0: RCCL unique id failed: %r" % (e,), file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
-        dev.comm_init(world, rank, uid[0])
+        try:
+            if uid[0] is None:
+                raise RuntimeError("no RCCL unique id")
+            dev.comm_init(world, rank, uid[0])
+        except Exception as e:
+            print("rank %d: hgibbs_comm_init (RCCL) failed: %r" % (rank, e), file=sys.stderr)
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not int(t[0]):
+            if rank == 0:
+                print("RCCL communicator not available on every rank: bulk reductions over gloo (host) instead", file=sys.stderr)
+            BULK = "gloo"
+            dev.close()
+            dev = capi.Device(local_rank)
+    if BULK == "gloo":
+        dev.comm_init_external(world, rank, allreduce)
     handle = None
     if want_p2p:
         try:
@@ -172,8 +215,9 @@ def exchange_self_check(capi, dist, world, rank, local_rank):
     lo, hi = min(Ns, rank * per), min(Ns, (rank + 1) * per)
     y = np.random.default_rng(7).normal(size=Ns)
     out = []
-    variants = (True,) if os.environ.get("HGIBBS_BENCH_BULK", "rccl") == "gloo" else (True, False)
-    for want_p2p in variants:
+    for want_p2p in (True, False):
+        if not want_p2p and BULK == "gloo":  # (decided by the first pass: no RCCL split path to compare with)
+            break
         ok = 1
         res = None
         try:
@@ -416,7 +460,7 @@ def main():
         if want_p2p and args.exchange == "auto":
             want_p2p = exchange_self_check(capi, dist, world, rank, local_rank)
         dev, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
-        exchange = "p2p-mailbox" if p2p else "rccl-allreduce"
+        exchange = "p2p-mailbox" if p2p else ("rccl-allreduce" if BULK == "rccl" else "gloo-allreduce (host)")
     else:
         dev = capi.Device(local_rank)
     if args.batch:
@@ -470,7 +514,7 @@ def main():
     anatomy_all = None
     if not args.no_anatomy:
         try:
-            anatomy_all = launch_anatomy(dev, chain)
+            anatomy_all = launch_anatomy(dev, chain, dist)
         except Exception as e:
             print("launch anatomy not measured: %r" % (e,), file=sys.stderr)
 
@@ -564,7 +608,7 @@ def main():
             "config": {"workload": "BayesRR %s: N=%d individuals x M=%d markers, K=%d mixture, G=%d groups, "
                                    ".bed resident in HBM, individuals sharded over %d GPU(s)"
                                    % (args.config, N, M, len(mS[0]), G, world),
-                       "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "nnz_updates_per_iter": nnz / K,
+                       "N": N, "M": M, "batch": args.batch or "auto", "exchange": exchange, "bulk_reductions": (BULK or "none"), "nnz_updates_per_iter": nnz / K,
                        "launches_per_iter": enqueued / K, "working_launches_per_iter": launches / K,
                        "accepted_per_launch": accepted / max(1, launches), "columns_streamed_per_accepted": streamed / max(1, accepted),
                        "carried_columns_per_iter": carried / K, "causal_frac": args.causal_frac,

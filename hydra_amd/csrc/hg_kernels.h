@@ -99,8 +99,9 @@ struct SweepDesc {
     double pend_ev[MAX_SEG][3]; // (dbeta, mave, mstd) of the pending updates: what the Gram correction of a carried dot needs
 };
 
-// Counters of a sweep, behind the descriptor in memory: the draw phase only ADDS to them (atomics without return), so that the
-// descriptor it hands to the next launch is written from registers without a load in front of it.
+// Counters of a sweep, behind the descriptor in memory and apart from it, so that the descriptor the draw phase hands to the next
+// launch is written from registers without a load in front of it.  One thread of the launch's last workgroup updates them with a
+// plain read-modify-write AFTER the hand-over (launches of a sweep are serial on the stream: no other writer).
 struct SweepCounters {
     unsigned long long nnz;           // markers with deltaBeta != 0 so far
     unsigned long long launches;      // launches that did work

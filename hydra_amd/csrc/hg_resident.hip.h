@@ -221,6 +221,37 @@ __device__ __forceinline__ int32_t rs_lane_ids()
     return v;
 }
 
+// The dot product's inner step for ONE column: four slots S .. S + 3 of a dword into four accumulators (field extract, int -> f64,
+// fused multiply-add, issued as three groups of four: three independent instructions between a producer and its consumer).
+// a_i += double((g >> 2 (4 Q + i)) & 3) * e[4 Q + i] -- the products are exact, one rounding per add.
+template <int Q>
+__device__ __forceinline__ void fma_col4(uint32_t g, const double (&e)[IPT], double& a0, double& a1, double& a2, double& a3)
+{
+    uint32_t t0, t1, t2, t3;
+    double w0, w1, w2, w3;
+    asm("v_bfe_u32 %[t0], %[g], %[s0], 2\n\t"
+        "v_bfe_u32 %[t1], %[g], %[s1], 2\n\t"
+        "v_bfe_u32 %[t2], %[g], %[s2], 2\n\t"
+        "v_bfe_u32 %[t3], %[g], %[s3], 2\n\t"
+        "v_cvt_f64_u32 %[w0], %[t0]\n\t"
+        "v_cvt_f64_u32 %[w1], %[t1]\n\t"
+        "v_cvt_f64_u32 %[w2], %[t2]\n\t"
+        "v_cvt_f64_u32 %[w3], %[t3]\n\t"
+        "v_fmac_f64 %[a0], %[w0], %[e0]\n\t"
+        "v_fmac_f64 %[a1], %[w1], %[e1]\n\t"
+        "v_fmac_f64 %[a2], %[w2], %[e2]\n\t"
+        "v_fmac_f64 %[a3], %[w3], %[e3]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)
+        : [g] "v"(g), [e0] "v"(e[4 * Q]), [e1] "v"(e[4 * Q + 1]), [e2] "v"(e[4 * Q + 2]), [e3] "v"(e[4 * Q + 3]), [s0] "i"(8 * Q), [s1] "i"(8 * Q + 2),
+          [s2] "i"(8 * Q + 4), [s3] "i"(8 * Q + 6));
+}
+template <int... Q>
+__device__ __forceinline__ void fma_col(uint32_t g, const double (&e)[IPT], double& a0, double& a1, double& a2, double& a3, std::integer_sequence<int, Q...>)
+{
+    (fma_col4<Q>(g, e, a0, a1, a2, a3), ...);
+}
+
 template <int T, int DBG>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
 {
@@ -379,56 +410,36 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (done_m) cols_landed(); // a second pass in one round (more than 8 RS_PF new columns): its columns are asked for here and now
             const uint32_t m = count_w < (uint32_t)RS_PF ? count_w : (uint32_t)RS_PF; // register sets in use this pass: k in [nk, nk + m)
             const int32_t ids = rs_lane_ids(); // lane r: marker id of set r's next column
-            auto quad = [&](auto gtag) __attribute__((always_inline)) {
-                constexpr int g = decltype(gtag)::value;
-                uint32_t kr[4];
-                bool act[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    kr[c] = nk + (((uint32_t)(4 * g + c) - nk) & (uint32_t)(RS_PF - 1));
-                    act[c] = kr[c] - nk < m;
-                }
-                if (act[0] || act[1] || act[2] || act[3]) { // wave-uniform
+            // one register set = one column: no arithmetic is spent on a set that is not this pass's (the sets in use are a circular
+            // run of m of the 16: taken four at a time, a quarter of the work was for columns not asked for -- and waves with one quad
+            // more than the others kept the workgroup's barrier waiting)
+            auto one = [&](auto rtag) __attribute__((always_inline)) {
+                constexpr int r = decltype(rtag)::value;
+                const uint32_t kr = nk + (((uint32_t)r - nk) & (uint32_t)(RS_PF - 1));
+                if (kr - nk < m) { // wave-uniform
                     double a[4] = {0.0, 0.0, 0.0, 0.0};
-                    uint32_t gw[4][T];
-                    rs_set_read<T, 4 * g + 0>(gw[0], keep);
-                    rs_set_read<T, 4 * g + 1>(gw[1], keep);
-                    rs_set_read<T, 4 * g + 2>(gw[2], keep);
-                    rs_set_read<T, 4 * g + 3>(gw[3], keep);
+                    uint32_t gw[T];
+                    rs_set_read<T, r>(gw, keep);
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
-                        fma_slots4(gw[0][t], gw[1][t], gw[2][t], gw[3][t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT>{});
+                    for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                    const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr));
+                    const uint32_t slot = pos & bmask;
+                    uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (act[c]) { // wave-uniform
-                            const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr[c]));
-                            const uint32_t slot = pos & bmask;
-                            uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-#pragma unroll
-                            for (int t = 0; t < T; ++t) rp[t] = gw[c][t];
-                            // the lane sums meet in eight-lane groups (three DPP steps, fixed order); the eight group sums go to LDS and
-                            // are added by ONE thread per column behind the barrier (in order: the dot does not depend on which wave took it)
-                            double v = a[c];
-                            v += rs_dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
-                            v += rs_dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
-                            v += rs_dpp_f64<0x141>(v); // row_half_mirror
-                            if ((lane & 7) == 0) part[(pos - Sx) * 8u + ((uint32_t)lane >> 3)] = v;
-                        }
-                    }
-                    // the quad's consumed sets take their next columns now: the loads leave HBM while the other quads are at work (no wait
-                    // is triggered by them: they are waited for by hand, at the top of the next round)
-                    if (!last) {
-                        if (act[0]) load_set(std::integral_constant<int, 4 * g + 0>{}, kr[0] + (uint32_t)RS_PF, ids);
-                        if (act[1]) load_set(std::integral_constant<int, 4 * g + 1>{}, kr[1] + (uint32_t)RS_PF, ids);
-                        if (act[2]) load_set(std::integral_constant<int, 4 * g + 2>{}, kr[2] + (uint32_t)RS_PF, ids);
-                        if (act[3]) load_set(std::integral_constant<int, 4 * g + 3>{}, kr[3] + (uint32_t)RS_PF, ids);
-                    }
+                    for (int t = 0; t < T; ++t) rp[t] = gw[t];
+                    // the lane sums meet in eight-lane groups (three DPP steps, fixed order); the eight group sums go to LDS and
+                    // are added by ONE thread per column behind the barrier (in order: the dot does not depend on which wave took it)
+                    double v = (a[0] + a[1]) + (a[2] + a[3]);
+                    v += rs_dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+                    v += rs_dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+                    v += rs_dpp_f64<0x141>(v); // row_half_mirror
+                    if ((lane & 7) == 0) part[(pos - Sx) * 8u + ((uint32_t)lane >> 3)] = v;
+                    // the consumed set takes its next column now: the load leaves HBM while the other sets are at work (no wait is
+                    // triggered by it: it is waited for by hand, at the top of the next round)
+                    if (!last) load_set(rtag, kr + (uint32_t)RS_PF, ids);
                 }
             };
-            quad(std::integral_constant<int, 0>{});
-            quad(std::integral_constant<int, 1>{});
-            quad(std::integral_constant<int, 2>{});
-            quad(std::integral_constant<int, 3>{});
+            [&]<int... R>(std::integer_sequence<int, R...>) { (one(std::integral_constant<int, R>{}), ...); }(std::make_integer_sequence<int, RS_PF>{});
             // (mave, mstd) of the columns just taken go to their window slots; the lanes take their next column's and the id of the one after
             {
                 const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));

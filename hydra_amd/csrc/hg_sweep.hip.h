@@ -381,8 +381,10 @@ __device__ __forceinline__ void sweep_draw_phase(const SweepParams& p, const Des
         mm.mstd = sh.mstd[tid];
         // dense BED form of the reference (src/BayesRRm.cpp:1785-1790,1809):
         // s1 = sum c1*(c2*eps), s2 = sum c2*eps, num = mstd*(s1 - mave*s2).
-        // A column without missing calls has s2 == sum of eps, bit for bit
-        // (same lanes, same order), so it is not accumulated per column.
+        // A column without missing calls has s2 == sum of eps: it is not accumulated per column.  p.eps_sum is reduced once at
+        // sweep start and held: an update adds dbeta times a standardised column, whose entries sum to zero, so the sum of eps
+        // moves by rounding only.  It is the running value within that rounding, not bit for bit; the host reduces eps again at
+        // sweep end and reports the gap (stats eps_sum_drift, asserted in tests; num moves by mstd*mave*drift at most).
         const double s1 = sh.tot[NR * tid];
         const double s2 = mm.miss ? sh.tot[NR * tid + 1] : p.eps_sum;
         sh.dp[tid] = mm.mstd * (s1 - mm.mave * s2);

@@ -1107,6 +1107,7 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     // an option that shapes the batch engine's launches asks for that engine (unless the caller has chosen one)
     for (const char* o : {"cols_per_group", "slices", "gram_missing", "graph", "max_seg", "ext_limit", "gram", "carry", "ahead", "force_split", "chunk"})
         if (!std::strcmp(name, o) && h->engine == 0) h->engine_pinned = true;
+    if (!std::strcmp(name, "batch") && value != 0 && h->engine == 0) h->engine_pinned = true; // a batch width (0 = auto names none)
     if (!std::strcmp(name, "batch")) {
         if (value < 0 || value > MAX_BATCH) return fail("batch must be in [0,%d] (0 = auto)", MAX_BATCH);
         h->batch = (uint32_t)value;

@@ -106,7 +106,9 @@ void read_option_file(const std::string& file, Options& o)
         else if (key == "save") o.save = (unsigned)std::stoi(value);
         else if (key == "S") {
             o.S.clear();
-            for (const std::string& t : tokens(value, " ,")) o.S.push_back(std::stod(t));
+            // (the reference reads these through stof, src/options.cpp:384: the option file's 0.0001 is 9.99999974737875e-05 in the chain,
+            // unlike --S on the command line, which goes through stod)
+            for (const std::string& t : tokens(value, " ,")) o.S.push_back((double)std::stof(t));
         } else if (key.substr(0, 2) == "//" || key.substr(0, 1) == "#") {
             continue;
         } else {

@@ -87,6 +87,9 @@ def test_inline_assembly_lds_reads_are_not_touched_before_their_wait(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_check.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "violations: 0" in r.stdout and "checked: 0," not in r.stdout
+    # (same script: every LDS-DMA load of a load-issue block comes before the block's plain loads, which is what the loops' hand-placed
+    # s_waitcnt vmcnt(N > 0) rely on)
+    assert "plain loads checked: 0" not in r.stdout
     # the resident sweep kernel lands its refill columns in hand-named registers (v216 .. v255) by loads the compiler does not see:
     # nothing it emits itself may name them (tools/asm_check_loads.py; hg_resident.hip.h)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_check_loads.py"), str(out)], capture_output=True, text=True)

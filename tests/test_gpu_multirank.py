@@ -180,3 +180,29 @@ def test_bayesw_two_ranks_one_gpu(with_cov):
     assert tol(np.concatenate([res[0][6], res[1][6]]), dev.get_residual())
     if with_cov:
         assert tol(res[0][8], ch.gamma()[0])
+
+
+def test_bench_two_ranks_under_the_launcher():
+    """The path the driver's multi-GPU run takes: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`,
+    here with both ranks on device 0 (HGIBBS_BENCH_DEVICE) and the bulk reductions over gloo (two processes cannot form an
+    RCCL communicator on one GPU).  The launcher is a child process started before this process's ranks touch the GPU; rank 0
+    prints exactly one JSON line that carries the contract's keys, the whole-job value and the exchange that ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HGIBBS_BENCH_BULK="gloo", HGIBBS_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--N", "40000", "--M", "4000",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["metric"] == "Gibbs markers/sec/iter"
+    assert d["unit"] == "markers/s" and d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert abs(d["value"] - 4000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["config"]["N"] == 40000 and d["config"]["M"] == 4000
+    assert d["config"]["exchange"] in ("p2p-mailbox", "gloo-allreduce (host)") and d["config"]["bulk_reductions"] == "gloo"
+    assert "roofline" in d and d["roofline"]["bound"] in ("latency", "hbm") and "cpu_baseline" in d

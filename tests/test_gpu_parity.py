@@ -472,16 +472,47 @@ def test_cli_end_to_end_files_match_oracle(oracle, tmp_path, grouped):
     assert struct.unpack("<II", xb[:8]) == (M, 4) and close(np.frombuffer(xb[8:], dtype=np.float64), betas[4])
 
 
+def test_cli_option_file_reads_S_as_float(oracle, tmp_path):
+    """--inp-file: the mixture variances of the option file go through stof (src/options.cpp:380-386), so the chain runs with
+    float32(0.0001) = 9.99999974737875e-05 and not with the double the command line's --S gives (stod, src/options.cpp:233)."""
+    M, N, iters = 90, 300, 4
+    geno = synth.make_genotypes(M, N, seed=41, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=42, causal_frac=0.1)
+    bed = synth.pack_bed_columns(geno)
+    prefix = str(tmp_path / "data")
+    synth.write_plink(prefix, bed, N, y=y, na_rows=[])
+    (tmp_path / "out").mkdir()
+    opt = tmp_path / "run.opt"
+    opt.write_text("analysisType RAM\nbayesType bayesMPI\nbedFile %s\nphenotypeFile %s.phen\nmcmcOut %s/out/run\n"
+                   "numberIndividuals %d\nnumberMarkers %d\nchainLength %d\nthin 1\nsave 100\nseed 1222\nshuffleMarkers 1\n"
+                   "S 0.0001,0.001,0.01\n" % (prefix, prefix, tmp_path, N, M, iters))
+    r = subprocess.run([EXE, "--inp-file", str(opt)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    s32 = np.float32([0.0001, 0.001, 0.01]).astype(np.float64)
+    assert s32[0] != 0.0001
+    _, betas = _read_bet(str(tmp_path / "out" / "run.bet"), M, np.float64)
+    _, comps = _read_bet(str(tmp_path / "out" / "run.cpn"), M, np.int32)
+    as_float = orc.Chain(oracle, bed, N, y, mS=np.array([[0.0, *s32]]), seed=1222)
+    as_double = orc.Chain(oracle, bed, N, y, mS=np.array([[0.0, 0.0001, 0.001, 0.01]]), seed=1222)
+    for it in range(iters):
+        as_float.iterate()
+        as_double.iterate()
+        assert np.array_equal(comps[it], as_float.arr("components")) and close(betas[it], as_float.arr("beta"), 1e-12)
+    # the two readings give different chains: the test would not pass with stod in the option file
+    assert np.max(np.abs(as_float.arr("beta") - as_double.arr("beta"))) > 1e-9
+
+
 def test_full_size_properties_c2():
     """BASELINE config 2 (N=50 000, M=100 000) through size-independent
     properties: (1) residual identity eps + X beta == y - mu after the sweep
-    (round trip through the update operator), (2) counts add up, (3) batch
-    width does not change a single bit of the chain."""
+    (round trip through the update operator), (2) counts add up, (3) neither the batch
+    width nor the engine (batch / resident) changes the chain, (4) the held sum of eps drifts by roundings only."""
     N, M = 50000, 100000
     res = []
-    for batch in (64, 17):
+    for batch in (64, 17, 0):
         dev = capi.Device(0)
-        dev.set_option("batch", batch)
+        if batch:
+            dev.set_option("batch", batch)  # pins the batch engine; the last pass runs the default, the resident engine
         dev.synth_bed(N, M, seed=42)
         rng = np.random.default_rng(1)
         y = rng.normal(size=N)
@@ -493,6 +524,8 @@ def test_full_size_properties_c2():
         ys = dev.get_residual()  # centred / scaled phenotype as the chain holds it
         for _ in range(2):
             ch.iterate()
+            ss = dev.sweep_stats()
+            assert ss["engine"] == (1 if batch else 2) and ss["eps_sum_drift"] <= 1e-9
         beta, comp, acum = dev.get_beta()
         st = ch.state()
         eps = dev.get_residual()
@@ -506,24 +539,27 @@ def test_full_size_properties_c2():
         assert np.max(np.abs(back - (ys - st["mu"]))) < 1e-8
         dev.close()
     # different batch widths cut the Gram-corrected extensions differently: equal up to fp rounding
-    assert np.array_equal(res[0][1], res[1][1]) and close(res[0][0], res[1][0]) and close(res[0][2], res[1][2])
-    assert close(res[0][3]["sigmaE"], res[1][3]["sigmaE"])
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and close(res[0][0], r[0]) and close(res[0][2], r[2])
+        assert close(res[0][3]["sigmaE"], r[3]["sigmaE"])
 
 
 @pytest.mark.parametrize("cfg", ["c3", "c4"])
 def test_full_size_properties_c3_c4(cfg):
     """BASELINE configs 3 (N=200 000, M=500 000, two groups) and 4 (N=500 000, M=1 000 000: 125 GB of packed
     genotypes in HBM) at full size through the same size-independent properties: counts add up, the residual
-    identity eps + X beta == y - mu holds after the sweeps (round trip through the update operator), and the
-    plain path (gram = 0, another batch width) walks the same chain as the Gram-corrected default."""
+    identity eps + X beta == y - mu holds after the sweeps (round trip through the update operator), and the three ways through
+    the sweep -- the resident engine (the default at these shapes), the batch engine with Gram corrections, and the batch
+    engine's plain path (gram = 0, another batch width) -- walk the same chain."""
     N, M, G = (200000, 500000, 2) if cfg == "c3" else (500000, 1000000, 1)
     groups = None if G == 1 else (np.arange(M) % 2).astype(np.int32)
     mS = np.array([[0.0, 0.0001, 0.001, 0.01]]) if G == 1 else np.array([[0.0, 0.001, 0.01, 0.1]] * 2)
     res = []
-    for batch, gram in ((256, 1), (200, 0)):
+    for batch, gram in ((0, 1), (256, 1), (200, 0)):
         dev = capi.Device(0)
-        dev.set_option("batch", batch)
-        dev.set_option("gram", gram)
+        if batch:  # naming a batch width pins the batch engine; without options the library picks the resident engine here
+            dev.set_option("batch", batch)
+            dev.set_option("gram", gram)
         dev.synth_bed(N, M, seed=42)
         rng = np.random.default_rng(1)
         dev.set_residual(rng.normal(size=N))
@@ -532,11 +568,17 @@ def test_full_size_properties_c3_c4(cfg):
         y = dev.get_residual()
         ch = capi.Chain(dev, y, mS=mS, groups=groups, seed=1222)
         ys = dev.get_residual()
+        drift = 0.0
         for _ in range(2):
             ch.iterate()
+            drift = max(drift, dev.sweep_stats()["eps_sum_drift"])
         beta, comp, acum = dev.get_beta()
         st, eps = ch.state(), dev.get_residual()
         res.append((beta, comp, eps, st))
+        # the sum of eps is reduced once per sweep and held (a standardised column sums to zero): what a sweep's roundings move
+        # it by, measured by the library at sweep end, stays far below the 1e-9 the dots are compared at
+        assert drift <= 1e-8 * max(1.0, abs(float(eps.sum()))), drift
+        assert dev.sweep_stats()["engine"] == (1 if batch else 2)
         assert st["cass"].sum() == M and st["m0"].sum() == (comp != 0).sum()
         assert np.all((beta != 0) == (comp != 0)) and np.all((acum >= 0) & (acum <= 1.0 + 1e-12))
         if gram:
@@ -544,8 +586,9 @@ def test_full_size_properties_c3_c4(cfg):
                 dev.update_marker(int(j), float(beta[j]))
             assert np.max(np.abs(dev.get_residual() - (ys - st["mu"]))) < 1e-8
         dev.close()
-    assert np.array_equal(res[0][1], res[1][1]) and close(res[0][0], res[1][0]) and close(res[0][2], res[1][2])
-    assert close(res[0][3]["sigmaE"], res[1][3]["sigmaE"]) and close(res[0][3]["sigmaG"], res[1][3]["sigmaG"])
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and close(res[0][0], r[0]) and close(res[0][2], r[2])
+        assert close(res[0][3]["sigmaE"], r[3]["sigmaE"]) and close(res[0][3]["sigmaG"], r[3]["sigmaG"])
 
 
 # ---------------------------------------------------------------------------

@@ -1,3 +1,8 @@
+#!/bin/bash
+# Quick kernel-trace of a short bench run on the batch engine (run on the GPU box from the repo root): per-launch durations of
+# k_sweep_batch into gpurun_out/kt1/stats.csv.
+set -euo pipefail
+cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/kt1
 rm -rf $O && mkdir -p $O

@@ -19,11 +19,14 @@ M = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 MISSING = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 VARIANTS = [("plain: gram=0, batch 200", {"gram": 0, "batch": 200}),
-            ("default", {}),
-            ("carry off", {"carry": 0}),
+            ("batch engine, defaults", {"engine": 1}),
+            ("resident engine", {"engine": 2}),
+            ("resident engine, window 64, predicted pivots", {"engine": 2, "window": 64, "pivots": 1}),
             ("carry on, ahead 64", {"carry": 1, "ahead": 64}),
             ("four segments, carry on, ahead 128", {"max_seg": 4, "carry": 1, "ahead": 128}),
             ("8 slices, cols_per_group 8", {"slices": 8, "cols_per_group": 8})]
+if MISSING > 0.0:  # the resident engine takes shards without missing calls (it refuses others)
+    VARIANTS = [v for v in VARIANTS if v[1].get("engine") != 2]
 devs = []
 for name, opts in VARIANTS:
     dev = capi.Device(0)
@@ -35,10 +38,12 @@ for name, opts in VARIANTS:
     devs.append((name, dev, ch))
 t0 = time.time()
 worst = 0.0
+drift = 0.0  # |sum of eps at sweep end - the sum reduced at sweep start and held|, largest over variants and iterations
 for it in range(ITERS):
     ref = None
     for name, dev, ch in devs:
         ch.iterate()
+        drift = max(drift, dev.sweep_stats()["eps_sum_drift"])
         beta, comp, _ = dev.get_beta()
         st = ch.state()
         if ref is None:
@@ -50,5 +55,5 @@ for it in range(ITERS):
         assert err <= 1e-9, "iteration %d: beta of '%s' off by %.3g" % (it, name, err)
         assert ch.last_nnz() == ref[3] and abs(st["sigmaE"] - ref[2]) <= 1e-9 * ref[2]
     if it % 5 == 4:
-        print("iteration %d: %d variants agree (nnz %d, worst relative beta difference so far %.2e, %.0f s)" % (it + 1, len(devs), ref[3], worst, time.time() - t0), flush=True)
-print("SOAK OK: N=%d M=%d missing %g, %d iterations, %d variants: %s" % (N, M, MISSING, ITERS, len(devs), "; ".join(n for n, _, _ in devs)))
+        print("iteration %d: %d variants agree (nnz %d, worst relative beta difference so far %.2e, eps-sum drift <= %.2e, %.0f s)" % (it + 1, len(devs), ref[3], worst, drift, time.time() - t0), flush=True)
+print("SOAK OK: N=%d M=%d missing %g, %d iterations, %d variants: %s; eps-sum drift <= %.3e" % (N, M, MISSING, ITERS, len(devs), "; ".join(n for n, _, _ in devs), drift))
