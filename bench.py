@@ -206,16 +206,17 @@ def make_multirank_device(capi, dist, world, rank, local_rank, want_p2p):
 
 
 def exchange_self_check(capi, dist, world, rank, local_rank):
-    """Run the same tiny sharded chain once with the peer-mailbox exchange and
-    once with the RCCL split path; the former is used for the timed run only if
-    it reproduces the latter (components exact, beta to 1e-9) on every rank."""
+    """Run the same tiny sharded chain three ways -- the resident engine over the peer mailboxes, the batch engine over the peer
+    mailboxes, the batch engine over the RCCL split path -- and decide what the timed run may use: the mailboxes only if the
+    batch engine reproduces the RCCL path with them, the resident engine only if it then reproduces the batch engine
+    (components exact, beta to 1e-9, on every rank).  Returns (use_p2p, use_resident)."""
     import torch
     Ns, Ms = 16384, 1500
     per = ((Ns + world - 1) // world + 3) // 4 * 4
     lo, hi = min(Ns, rank * per), min(Ns, (rank + 1) * per)
     y = np.random.default_rng(7).normal(size=Ns)
-    out = []
-    for want_p2p in (True, False):
+    out = {}
+    for name, want_p2p, opts in (("batch-p2p", True, {"batch": 64}), ("resident-p2p", True, {"engine": 2}), ("batch-split", False, {"batch": 64})):
         if not want_p2p and BULK == "gloo":  # (decided by the first pass: no RCCL split path to compare with)
             break
         ok = 1
@@ -224,7 +225,8 @@ def exchange_self_check(capi, dist, world, rank, local_rank):
             d, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
             if want_p2p and not p2p:
                 raise RuntimeError("p2p import failed on some rank")
-            d.set_option("batch", 64)
+            for k, v in opts.items():
+                d.set_option(k, v)
             d.synth_bed(Ns, Ms, seed=5, row_begin=lo, row_end=hi)
             ch = capi.Chain(d, y, seed=99)
             for _ in range(2):
@@ -232,19 +234,24 @@ def exchange_self_check(capi, dist, world, rank, local_rank):
             res = d.get_beta()[:2]
             d.close()
         except Exception as e:
-            print("rank %d: exchange self-check (%s) failed: %r" % (rank, "p2p" if want_p2p else "rccl", e), file=sys.stderr)
+            print("rank %d: exchange self-check (%s) failed: %r" % (rank, name, e), file=sys.stderr)
             ok = 0
         t = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        out.append(res if int(t[0]) else None)
-    if len(out) == 1:
-        return out[0] is not None
-    if out[0] is None or out[1] is None:
-        return out[0] is not None and out[1] is None  # p2p only if it is the one that works
-    same = np.array_equal(out[0][1], out[1][1]) and np.all(np.abs(out[0][0] - out[1][0]) <= 1e-9 * np.maximum(1.0, np.abs(out[1][0])))
-    t = torch.tensor([1 if same else 0], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(int(t[0]))
+        out[name] = res if int(t[0]) else None
+
+    def same(a, b):
+        eq = a is not None and b is not None and np.array_equal(a[1], b[1]) and bool(np.all(np.abs(a[0] - b[0]) <= 1e-9 * np.maximum(1.0, np.abs(b[0]))))
+        t = torch.tensor([1 if eq else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    if "batch-split" in out and out["batch-split"] is not None:
+        use_p2p = same(out["batch-p2p"], out["batch-split"])
+    else:
+        use_p2p = out["batch-p2p"] is not None  # the mailboxes are the transport that works
+    use_resident = use_p2p and same(out["resident-p2p"], out["batch-p2p"])
+    return use_p2p, use_resident
 
 
 def cpu_model():
@@ -457,10 +464,13 @@ def main():
     exchange = "none"
     if world > 1:
         want_p2p = args.exchange in ("auto", "p2p") and os.environ.get("HGIBBS_DISABLE_P2P", "0") != "1"
+        resident_ok = True
         if want_p2p and args.exchange == "auto":
-            want_p2p = exchange_self_check(capi, dist, world, rank, local_rank)
+            want_p2p, resident_ok = exchange_self_check(capi, dist, world, rank, local_rank)
         dev, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
         exchange = "p2p-mailbox" if p2p else ("rccl-allreduce" if BULK == "rccl" else "gloo-allreduce (host)")
+        if not resident_ok:
+            dev.set_option("engine", 1)  # the resident engine's cross-rank sums did not reproduce the batch engine's here: not used
     else:
         dev = capi.Device(local_rank)
     if args.batch:

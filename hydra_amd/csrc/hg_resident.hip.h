@@ -43,6 +43,7 @@ constexpr int RS_TRACE = 4096;            // messages whose stamps the debug bui
 constexpr int RS_TMAX = 2;                // most wave tiles per workgroup (16 T doubles of eps per lane, in every wave; a build for 4 spills registers)
 constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
+constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marker was an event (the walker wrote its component); cleared by k_res_finish
 
 enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has); RS_LAST is a flag bit
 
@@ -101,7 +102,28 @@ struct ResParams {
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
+    // several GPUs (individuals sharded over the ranks): every rank runs this kernel on its shard, the walkers are
+    // replicas that decide on the SAME integer sums -- each adds its peers' parts, which arrive in its mailbox (RX_* below)
+    int nranks, rank;
+    unsigned char* mbox[MAX_RANKS]; // mbox[r]: rank r's resident mailbox (IPC-mapped; [rank] is local memory)
+    unsigned long long sweep_id;    // this sweep's epoch in the mailbox flags (the ranks count their sweeps alike)
 };
+
+// Resident mailbox of a rank, written by its peers with system-scope 8-byte stores (xGMI; uncached memory).  Indexed by the SENDER's rank:
+//   gbox[src][parity][RS_BMAX] u64   sweep_id << 48 | n << 24 | the sender's sum over its workgroups of the Gram terms of event n (parity n & 1):
+//                                    self-validating words, no flag
+//   rbox[src][RX_RING][2] u64        the sender's sum of the raw dots (fixed point, 64 bits) of position p, at p mod RX_RING, as two
+//                                    words tag << 32 | low half, tag << 32 | high half with tag = 1 (never the zero of fresh memory) | sweep (11 bits) | the position's refill batch (20)
+// Every word says itself what it is: no flag has to be ordered behind the data (one hop; the reader polls the words it needs).
+// A peer is never more than one event ahead (it needs this rank's part of event n + 1 to get past it) nor more than a window's
+// worth of positions (a position's dot needs every rank's part): two parities and a ring of four windows are enough.
+constexpr uint32_t RX_RING = 1024;
+constexpr size_t RX_GBOX = 0;
+constexpr size_t RX_RBOX = RX_GBOX + (size_t)MAX_RANKS * 2 * RS_BMAX * 8;
+constexpr size_t RX_BYTES = RX_RBOX + (size_t)MAX_RANKS * RX_RING * 16;
+__device__ __forceinline__ unsigned long long* rx_gbox(unsigned char* mb, int src, uint32_t par) { return reinterpret_cast<unsigned long long*>(mb + RX_GBOX) + ((size_t)src * 2 + par) * RS_BMAX; }
+__device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_RBOX) + (size_t)src * RX_RING * 2; }
+__device__ __forceinline__ unsigned long long rx_rtag(unsigned long long sweep, uint32_t batch) { return (0x80000000ull | ((sweep & 0x7ffull) << 20) | (unsigned long long)(batch & 0xfffffu)) << 32; }
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u4_t rs_load16(const void* p)
@@ -602,9 +624,9 @@ struct WalkShared {
     uint8_t* ekq;     // [B] its component
     uint8_t* ada;
     uint8_t* fdone; // the slot's raw dot has arrived
+    unsigned long long* rloc; // [B] several ranks: this rank's part of the slot's raw dot (pushed to the peers; the dot needs theirs)
+    uint8_t* fpush;           // [B] ... has been taken and pushed
     unsigned char* end;
-    double* ebuf;   // [RS_BLOCK] exp(logL_l - logL_0) of the chunk under evaluation
-    uint8_t* bigf;  // [RS_BLOCK]
     double* fd;     // 64 doubles of scratch (event: dbeta, bnew, prob, ...)
     uint32_t* fl;   // 64 words of flags
     int32_t* lcass; // [256]
@@ -626,10 +648,10 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.dpr = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.thr0 = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.num = reinterpret_cast<double*>(q); q += (size_t)B * 8;
-    s.ebuf = reinterpret_cast<double*>(q); q += (size_t)RS_BLOCK * 8;
     s.rprev = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
     s.pf_val = reinterpret_cast<double*>(q); q += (size_t)RS_PFIRE * 3 * 8;
     s.ebn = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.rloc = reinterpret_cast<unsigned long long*>(q); q += (size_t)B * 8;
     s.tq = reinterpret_cast<double*>(q); q += (size_t)MT_BUF * 8;
     s.qtab = reinterpret_cast<double*>(q); q += (size_t)2 * HT_LDS * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
@@ -647,9 +669,9 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.crank = reinterpret_cast<uint16_t*>(q); q += (size_t)RS_BMAX * 2;
     s.bl_np = q; q += RS_NB;
     s.ekq = q; q += B;
-    s.bigf = q; q += RS_BLOCK;
     s.ada = q; q += B;
     s.fdone = q; q += B;
+    s.fpush = q; q += B;
     s.end = q;
     return s;
 }
@@ -664,7 +686,6 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     const int K = p.K;
     const bool lds_tab = p.GK <= HT_LDS;
     const WalkShared sh = walk_carve(smem, B);
-    const uint32_t EV = (uint32_t)RS_BLOCK / (uint32_t)K; // markers evaluated per chunk: one thread per (marker, component)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = wall_clock64();
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = DBG ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
@@ -720,6 +741,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.mstd[slot] = p.s_mstd[j];
             sh.dp[slot] = 0.0;
             sh.fdone[slot] = 0;
+            sh.fpush[slot] = 0;
             sh.batch[slot] = batch;
         }
     };
@@ -783,15 +805,39 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             atomicMin(&sh.fl[WF_FMIN], j);
             return;
         }
-        unsigned long long* base = p.racc + (j % RS_RB);
-        unsigned long long w[RS_RSH];
+        unsigned long long tot;
+        if (p.nranks > 1) { // this rank's part was taken by push_raw (same thread, same pass); the peers' parts: two self-validating words each
+            const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
+            unsigned long long o[MAX_RANKS][2];
 #pragma unroll
-        for (int s = 0; s < RS_RSH; ++s) w[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
-        unsigned long long now = 0ull;
+            for (int r = 0; r < MAX_RANKS; ++r) {
+                const bool on = r < p.nranks && r != p.rank;
+                const unsigned long long* w = rx_rbox(p.mbox[p.rank], on ? r : p.rank) + 2u * (j % RX_RING);
+                o[r][0] = on ? __hip_atomic_load(w, HG_RLX_SYSTEM) : tag;
+                o[r][1] = on ? __hip_atomic_load(w + 1, HG_RLX_SYSTEM) : tag;
+            }
+            bool all = true;
+            tot = sh.rloc[slot];
 #pragma unroll
-        for (int s = 0; s < RS_RSH; ++s) now += w[s];
-        const unsigned long long tot = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic)
-        sh.rprev[j % RS_RB] = now;
+            for (int r = 0; r < MAX_RANKS; ++r) {
+                all = all && (o[r][0] >> 32) == (tag >> 32) && (o[r][1] >> 32) == (tag >> 32);
+                tot += (o[r][1] << 32) | (o[r][0] & 0xffffffffull);
+            }
+            if (!all) { // a peer's part is still on its way
+                atomicMin(&sh.fl[WF_FMIN], j);
+                return;
+            }
+        } else {
+            unsigned long long* base = p.racc + (j % RS_RB);
+            unsigned long long w[RS_RSH];
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) w[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
+            unsigned long long now = 0ull;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) now += w[s];
+            tot = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic)
+            sh.rprev[j % RS_RB] = now;
+        }
         const double s1 = (double)(long long)tot * p.fx_unscale;
         sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
         // the column's Gram terms with its batch's pivots (those in front of it), and the corrections of the pivots that have fired since
@@ -817,12 +863,37 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         }
         sh.fdone[slot] = 1;
     };
+    // several ranks: this rank's part of the raw dot of position j (its batch complete here), kept and pushed to every peer
+    auto push_raw = [&](uint32_t j, uint32_t done) {
+        const uint32_t slot = j & bmask;
+        if (sh.fpush[slot] || sh.batch[slot] >= done) return;
+        unsigned long long* base = p.racc + (j % RS_RB);
+        unsigned long long w[RS_RSH];
+#pragma unroll
+        for (int s = 0; s < RS_RSH; ++s) w[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
+        unsigned long long now = 0ull;
+#pragma unroll
+        for (int s = 0; s < RS_RSH; ++s) now += w[s];
+        const unsigned long long tot = now - sh.rprev[j % RS_RB];
+        sh.rprev[j % RS_RB] = now;
+        sh.rloc[slot] = tot;
+        const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
+        for (int r = 0; r < p.nranks; ++r)
+            if (r != p.rank) {
+                unsigned long long* w = rx_rbox(p.mbox[r], p.rank) + 2u * (j % RX_RING);
+                __hip_atomic_store(w, tag | (tot & 0xffffffffull), HG_RLX_SYSTEM);
+                __hip_atomic_store(w + 1, tag | (tot >> 32), HG_RLX_SYSTEM);
+            }
+        sh.fpush[slot] = 1;
+    };
     // one pass over the positions [F, Sx) that have no dot yet; afterwards F = the first one still missing
     auto fold_pass = [&]() {
         refresh_batches();
         if (tid == 0) sh.fl[WF_FMIN] = Sx;
         __syncthreads();
         const uint32_t done = sh.fl[WF_RDONE];
+        if (p.nranks > 1)
+            for (uint32_t j = F + (uint32_t)tid; j < Sx; j += RS_BLOCK) push_raw(j, done);
         for (uint32_t j = F + (uint32_t)tid; j < Sx; j += RS_BLOCK) try_raw(j, done);
         __syncthreads();
         F = sh.fl[WF_FMIN];
@@ -874,9 +945,43 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                 gp[3] = d.w & RS_LOW;
             }
             __syncthreads();
-            if ((uint32_t)tid < gV) {
-                uint32_t A = 0u;
+            uint32_t A = 0u;
+            if ((uint32_t)tid < gV)
                 for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart[sidx * RS_BMAX + (uint32_t)tid];
+            if (p.nranks > 1) {
+                // this rank's sums go to every peer's mailbox, the peers' arrive in mine (integers: the total does not depend on the
+                // order).  A word says itself what it is -- sweep << 48 | event << 24 | sum, one 8-byte store -- so there is no flag
+                // to order behind the data: one hop, and the reader polls the words it needs.
+                const unsigned long long tag = (p.sweep_id << 48) | ((unsigned long long)(nev & 0xffffffu) << 24);
+                if ((uint32_t)tid < gV) {
+                    for (int r = 0; r < p.nranks; ++r)
+                        if (r != p.rank) __hip_atomic_store(rx_gbox(p.mbox[r], p.rank, par) + tid, tag | (unsigned long long)A, HG_RLX_SYSTEM);
+                    const unsigned long long t0 = wall_clock64();
+                    for (;;) {
+                        unsigned long long o[MAX_RANKS];
+#pragma unroll
+                        for (int r = 0; r < MAX_RANKS; ++r)
+                            o[r] = (r < p.nranks && r != p.rank) ? __hip_atomic_load(rx_gbox(p.mbox[p.rank], r, par) + tid, HG_RLX_SYSTEM) : tag;
+                        bool all = true;
+                        uint32_t add = 0u;
+#pragma unroll
+                        for (int r = 0; r < MAX_RANKS; ++r) {
+                            all = all && (o[r] >> 24) == (tag >> 24);
+                            add += (uint32_t)o[r] & RS_LOW;
+                        }
+                        if (all) {
+                            A += add;
+                            break;
+                        }
+                        if (wall_clock64() - t0 > p.timeout) {
+                            sh.fl[WF_ABORT] = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if ((uint32_t)tid < gV) {
                 const uint32_t slot = (gq + 1u + (uint32_t)tid) & bmask;
                 const double mj = sh.mave[slot], sj = sh.mstd[slot];
                 const double xx = sj * g_mstd * ((double)A - p.n_total * (mj * g_mave));
@@ -1166,59 +1271,25 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             ++n_adv;
         }
 
-        // 5. results of the consumed markers (:1892,:1899-1905,:1924-1925) -- Acum = 1 / sum_l exp(logL_l - logL_0) with the reference's
-        // arithmetic, one thread per (marker, component), off the chain: the streaming workgroups are busy with the message -- then
-        // their slots go to the refill
-        for (uint32_t b0 = C; b0 < Cn; b0 += EV) {
-            const uint32_t nevl = (Cn - b0 < EV) ? Cn - b0 : EV;
-            {
-                const uint32_t jj = (uint32_t)tid / (uint32_t)K;
-                const int l = (int)((uint32_t)tid % (uint32_t)K);
-                if (jj < nevl) {
-                    const uint32_t slot = (b0 + jj) & bmask;
-                    if (sh.ada[slot]) {
-                        const int g0 = sh.grp[slot] * K;
-                        const double num = sh.num[slot];
-                        const double L0 = tabv(1, g0);
-                        double L = L0;
-                        if (l > 0) {
-                            const double mk = num / tabv(0, g0 + l);
-                            L = tabv(1, g0 + l) - tabv(2, g0 + l) + mk * num * p.i_2sigE;
-                        }
-                        const double d = L - L0;
-                        sh.ebuf[tid] = exp(d);
-                        sh.bigf[tid] = (uint8_t)((l >= 1 && fabs(d) > 700.0) ? 1 : 0);
-                    }
-                }
+        // 5. results of the consumed markers: the numerator of every marker that took part goes out as it stands (Acum's slot holds it
+        // until the sweep is over: k_res_finish turns it into Acum = 1 / sum_l exp(logL_l - logL_0), :1892,:1899-1905, for all markers at
+        // once -- K exponentials per marker are not the walker's business while the chain waits for it); an event also writes its new
+        // effect and its component (flagged: k_res_finish clears the flag, gives every other marker component 0 and counts those)
+        for (uint32_t j = C + (uint32_t)tid; j < Cn; j += RS_BLOCK) {
+            const uint32_t slot = j & bmask;
+            if (DBG) { // the dot as streamed and its Gram corrections, by sweep position (tools/dbg_res.py)
+                p.trace[8 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dpr[slot]);
+                p.trace[9 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dp[slot]);
             }
-            __syncthreads();
-            if ((uint32_t)tid < nevl) {
-                const uint32_t j = b0 + (uint32_t)tid;
-                const uint32_t slot = j & bmask;
+            if (sh.ada[slot]) {
                 const int marker = sh.marker[slot];
-                const bool isq = found && j == qpos;
-                if (DBG) { // the dot as streamed and its Gram corrections, by sweep position (tools/dbg_res.py)
-                    p.trace[8 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dpr[slot]);
-                    p.trace[9 * RS_TRACE + j % RS_TRACE] = (unsigned long long)__double_as_longlong(sh.dp[slot]);
-                }
-                if (sh.ada[slot]) {
-                    double sum = 0.0;
-                    bool big = false;
-                    for (int l = 0; l < K; ++l) {
-                        sum += sh.ebuf[(uint32_t)tid * (uint32_t)K + (uint32_t)l];
-                        big = big || sh.bigf[(uint32_t)tid * (uint32_t)K + (uint32_t)l] != 0;
-                    }
-                    const int kk = isq ? kq : 0;
-                    p.beta[marker] = isq ? bnew : 0.0;
-                    p.comp[marker] = kk;
-                    p.acum[marker] = big ? 0.0 : 1.0 / sum;
-                    atomicAdd(&sh.lcass[sh.grp[slot] * K + kk], 1);
-                } else {
-                    p.beta[marker] = 0.0;
-                    p.acum[marker] = 1.0;
+                p.acum[marker] = sh.num[slot];
+                if (found && j == qpos) {
+                    p.beta[marker] = bnew;
+                    p.comp[marker] = kq | RS_EVENT_FLAG;
+                    atomicAdd(&sh.lcass[sh.grp[slot] * K + kq], 1);
                 }
             }
-            __syncthreads();
         }
         if (tid == 0) {
             sh.fl[WF_FOUND] = 0u;
@@ -1296,6 +1367,52 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         if (DBG)
             for (int i = 0; i < 8; ++i) st->t[i] = tacc[i];
     }
+}
+
+// Behind the sweep, one thread per sweep position: the marker's numerator (left in Acum's slot by the walker) becomes
+// Acum = 1 / sum_l exp(logL_l - logL_0) with the reference's arithmetic and order (:1883-1905: logL_0 = logpi_0,
+// logL_l = logpi_l - hlog_l + (num / denom_l) num / (2 sigmaE); a difference beyond 700 makes it 0); a marker that was no event
+// has component 0 and counts for cass[group][0] (the walker counted the events); one outside the adaptive set gets effect 0, Acum 1.
+__global__ __launch_bounds__(256) void k_res_finish(ResParams p)
+{
+    __shared__ int lc[256]; // GK <= 256 (resident_plan)
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lc[i] = 0;
+    __syncthreads();
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < p.M) {
+        const int ga = p.s_ga[j], marker = p.order[j], K = p.K;
+        if (ga & 0x40000000) {
+            const int g0 = (ga & 0x0fffffff) * K;
+            const double num = p.acum[marker];
+            const double L0 = p.logpi[g0];
+            double sum = 0.0;
+            bool big = false;
+            for (int l = 0; l < K; ++l) {
+                double L = L0;
+                if (l > 0) {
+                    const double mk = num / p.denom[g0 + l];
+                    L = p.logpi[g0 + l] - p.hlog[g0 + l] + mk * num * p.i_2sigE;
+                }
+                const double d = L - L0;
+                sum += exp(d);
+                big = big || (l >= 1 && fabs(d) > 700.0);
+            }
+            p.acum[marker] = big ? 0.0 : 1.0 / sum;
+            const int c = p.comp[marker];
+            if (c & RS_EVENT_FLAG) {
+                p.comp[marker] = c & (RS_EVENT_FLAG - 1);
+            } else {
+                p.comp[marker] = 0;
+                atomicAdd(&lc[g0], 1);
+            }
+        } else {
+            p.beta[marker] = 0.0;
+            p.acum[marker] = 1.0;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.GK; i += blockDim.x)
+        if (lc[i]) atomicAdd(p.cass + i, lc[i]);
 }
 
 template <int T, int DBG>

@@ -146,6 +146,7 @@ struct hgibbs_ctx {
 
     // resident engine (hg_resident.hip.h): one launch per sweep, individuals sharded over the compute units
     int engine = 0;           // option engine: 0 auto (resident where it applies), 1 batch engine (k_sweep_batch), 2 resident (refused where it does not apply)
+    unsigned long long res_sweep_id = 0; // resident sweeps so far: the epoch of the cross-rank mailbox flags
     bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
@@ -176,7 +177,9 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
 static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4, RES_PACC_BYTES = (size_t)RS_RSH * RS_PMAX * RS_RB * 4;
 static constexpr size_t RES_ACC_BYTES = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES + RES_PACC_BYTES;
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
-static constexpr size_t MBOX_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long);
+static constexpr size_t MBOX_BATCH_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long); // the batch engine's rows and flags
+static constexpr size_t MBOX_RES_OFF = (MBOX_BATCH_BYTES + 4095) / 4096 * 4096;                                  // behind them the resident engine's mailbox (hg_resident.hip.h, RX_*)
+static constexpr size_t MBOX_BYTES = MBOX_RES_OFF + RX_BYTES;
 
 // Sum a device buffer over ranks (rare, bulk): RCCL when a communicator exists,
 // else the caller's transport on a host copy.  dtype 0 = f64, 1 = u64.
@@ -1230,7 +1233,7 @@ struct ResPlan {
 static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
 {
     pl->ok = false;
-    if (h->nranks > 1) return "several ranks (the exchange lives in the batch engine)";
+    if (h->nranks > 1 && !(h->p2p_ready && h->p2p_enabled)) return "several ranks without peer mailboxes (hgibbs_p2p_import): the RCCL / host exchange lives in the batch engine";
     if (h->force_split) return "force_split";
     if (h->any_missing) return "columns with missing calls";
     if (h->G * h->K > 256 || h->K > MAX_K || h->K < 2) return "mixture size";
@@ -1298,7 +1301,8 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         // individuals (Cauchy-Schwarz, with the sum of squares of ALL individuals); the scale leaves a factor 8 for what the
         // sweep's own updates add, and a contribution that would not fit is refused by the kernel (error 5), never wrapped.
         // Resolution: 1 / fx_scale (~1e-10 at config 4 against dots of order 10^2..10^3)
-        const double bound = 16.0 * std::sqrt(1024.0 * pl.T * std::max(r0[1], 1e-300)) + 1.0;
+        // (several ranks: the same scale everywhere -- the largest workgroup any rank may have; the sum of squares is over all ranks)
+        const double bound = 16.0 * std::sqrt(1024.0 * (h->nranks > 1 ? RS_TMAX : pl.T) * std::max(r0[1], 1e-300)) + 1.0;
         int ex = 50 - (int)std::ceil(std::log2(bound));
         ex = std::max(-40, std::min(ex, 60));
         p.fx_scale = std::ldexp(1.0, ex);
@@ -1306,7 +1310,11 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     }
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.dbg = h->debug_timing ? 1 : 0;
-    p.pivots = h->res_pivots;
+    p.pivots = h->nranks > 1 ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange)
+    p.nranks = h->nranks > 1 ? h->nranks : 1;
+    p.rank = h->nranks > 1 ? h->rank : 0;
+    for (int r = 0; r < MAX_RANKS; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
+    p.sweep_id = ++h->res_sweep_id; // every rank runs the same sweeps on the resident engine (agreed in hgibbs_sweep): the counters stay equal
     p.trace = h->res_trace;
     p.progress = h->res_progress;
     HIP_TRY(hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream));
@@ -1338,6 +1346,8 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         std::fprintf(stderr, "[hgibbs] resident sweep: T %d, %u streaming workgroups, window %u, LDS %zu B, fixed-point scale 2^%d\n", pl.T, pl.W, pl.B, lds, (int)std::log2(p.fx_scale));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    k_res_finish<<<dim3((h->M + 255u) / 256u), 256, 0, h->stream>>>(p); // numerators -> Acum, components and cass of the markers that were no event
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipMemcpyAsync(h->res_state_host, h->res_state, sizeof(ResState), hipMemcpyDeviceToHost, h->stream));
@@ -1469,8 +1479,21 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     ResPlan plan{};
     {
         const char* why = resident_plan(h, &plan);
-        if (h->engine == 2 && why) return fail("hgibbs_sweep: the resident engine does not apply: %s", why);
         if (h->engine == 1 || (h->engine == 0 && h->engine_pinned)) plan.ok = false;
+        if (h->nranks > 1) {
+            // the ranks run ONE engine: the resident one only if every rank can (a rank with a larger shard, another option or no
+            // mailbox would otherwise wait for peers that are in the other engine's exchange)
+            h->scratch_host[0] = plan.ok ? 0.0 : 1.0;
+            HIP_TRY(hipMemcpyAsync(h->sums, h->scratch_host, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            if (bulk_allreduce(h, h->sums, 1, 0)) return 1;
+            HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->scratch_host[0] != 0.0) {
+                if (plan.ok) why = "another rank cannot run it";
+                plan.ok = false;
+            }
+        }
+        if (h->engine == 2 && !plan.ok) return fail("hgibbs_sweep: the resident engine does not apply: %s", why ? why : "the batch engine was asked for by an option");
         if (std::getenv("HGIBBS_DEBUG"))
             std::fprintf(stderr, "[hgibbs] engine: %s%s%s\n", plan.ok ? "resident" : "batch", why ? " -- resident refused: " : "", why ? why : "");
     }

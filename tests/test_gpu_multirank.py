@@ -26,7 +26,7 @@ def _shard(N, world, rank):
     return min(N, rank * per), min(N, (rank + 1) * per)
 
 
-def _worker(rank, world, port, bed, y, N, iters, batch, q):
+def _worker(rank, world, port, bed, y, N, iters, opts, q):
     import torch
     import torch.distributed as dist
     from hydra_amd import capi
@@ -49,13 +49,16 @@ def _worker(rank, world, port, bed, y, N, iters, batch, q):
         dev.p2p_import(handles)
         lo, hi = _shard(N, world, rank)
         dev.load_bed(bed, N, row_begin=lo, row_end=hi, n_global=N)
-        dev.set_option("batch", batch)
+        for k, v in opts.items():
+            dev.set_option(k, v)
         ch = capi.Chain(dev, y, seed=1222)
+        engines = set()
         for _ in range(iters):
             ch.iterate()
+            engines.add(dev.sweep_stats()["engine"])
         beta, comp, acum = dev.get_beta()
         st = ch.state()
-        q.put((rank, beta, comp, st["sigmaE"], st["sigmaG"], dev.get_residual(), ch.last_nnz()))
+        q.put((rank, beta, comp, st["sigmaE"], st["sigmaG"], dev.get_residual(), ch.last_nnz(), sorted(engines), acum, st["cass"]))
     except Exception as e:  # surface the error text in the parent
         q.put((rank, repr(e)))
     finally:
@@ -77,14 +80,15 @@ def test_two_ranks_one_gpu_p2p_exchange(batch, M, N, world, miss):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, batch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, {"batch": batch}, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for r in res:
-        assert len(r) == 7, "rank %s failed: %s" % (r[0], r[1])
+        assert len(r) == 10, "rank %s failed: %s" % (r[0], r[1])
+        assert r[7] == [1]
     res.sort(key=lambda r: r[0])
 
     dev = capi.Device(0)
@@ -105,6 +109,44 @@ def test_two_ranks_one_gpu_p2p_exchange(batch, M, N, world, miss):
     eps = np.concatenate([r[5] for r in res])
     assert np.allclose(eps, dev.get_residual(), rtol=0, atol=1e-9)
     assert res[0][6] == ch.last_nnz()
+
+
+@pytest.mark.parametrize("M,N,world,opts", [(400, 9000, 2, {}), (500, 21000, 3, {"window": 64}), (300, 30000, 2, {"res_cus": 9})])
+def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts):
+    """The resident engine sharded over ranks (here: processes that share device 0; the mailboxes are IPC-mapped memory as between
+    GPUs): every rank runs one resident kernel on its shard, the walkers are replicas that add the peers' integer Gram sums and
+    fixed-point raw dots from their mailboxes.  Replicas bit-identical; equal to the CPU oracle's chain on the whole data
+    (components, cass exact; beta, Acum, residual to 1e-9).  Ragged shards (three ranks), a small window, two tiles per workgroup."""
+    import torch.multiprocessing as mp
+    import orc
+    from hydra_amd import synth
+    iters = 3
+    geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=72, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, dict(opts, engine=2), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert len(r) == 10, "rank %s failed: %s" % (r[0], r[1])
+        assert r[7] == [2]
+    res.sort(key=lambda r: r[0])
+    ref = orc.Chain(oracle, bed, N, y, seed=1222)
+    for _ in range(iters):
+        ref.iterate()
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]) and res[0][3] == r[3] and np.array_equal(res[0][8], r[8])
+    tol = lambda a, b: np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-9 * np.maximum(1.0, np.abs(np.asarray(b))))
+    assert np.array_equal(res[0][2], ref.arr("components")) and np.array_equal(np.asarray(res[0][9]).ravel(), ref.arr("cass"))
+    assert tol(res[0][1], ref.arr("beta")) and tol(res[0][8], ref.arr("acum")) and tol(res[0][3], ref.sigmaE)
+    assert tol(np.concatenate([r[5] for r in res]), ref.arr("eps"))
+    assert res[0][6] == oracle.orc_chain_last_nnz(ref.h)
 
 
 # ---- BayesW sharded the same way: per-batch row sums and the density sums add over the ranks ----------
