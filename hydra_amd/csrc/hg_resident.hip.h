@@ -43,6 +43,7 @@ constexpr int RS_TRACE = 4096;            // messages whose stamps the debug bui
 constexpr int RS_TMAX = 2;                // most wave tiles per workgroup (16 T doubles of eps per lane, in every wave; a build for 4 spills registers)
 constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
+constexpr int RX_MAXR = 8;                // ranks the engine shards over (one node of eight GPUs; more fall back to the batch engine): the walker keeps a load per peer in flight
 constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marker was an event (the walker wrote its component); cleared by k_res_finish
 
 enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has); RS_LAST is a flag bit
@@ -105,7 +106,7 @@ struct ResParams {
     // several GPUs (individuals sharded over the ranks): every rank runs this kernel on its shard, the walkers are
     // replicas that decide on the SAME integer sums -- each adds its peers' parts, which arrive in its mailbox (RX_* below)
     int nranks, rank;
-    unsigned char* mbox[MAX_RANKS]; // mbox[r]: rank r's resident mailbox (IPC-mapped; [rank] is local memory)
+    unsigned char* mbox[RX_MAXR]; // mbox[r]: rank r's resident mailbox (IPC-mapped; [rank] is local memory)
     unsigned long long sweep_id;    // this sweep's epoch in the mailbox flags (the ranks count their sweeps alike)
 };
 
@@ -119,8 +120,8 @@ struct ResParams {
 // worth of positions (a position's dot needs every rank's part): two parities and a ring of four windows are enough.
 constexpr uint32_t RX_RING = 1024;
 constexpr size_t RX_GBOX = 0;
-constexpr size_t RX_RBOX = RX_GBOX + (size_t)MAX_RANKS * 2 * RS_BMAX * 8;
-constexpr size_t RX_BYTES = RX_RBOX + (size_t)MAX_RANKS * RX_RING * 16;
+constexpr size_t RX_RBOX = RX_GBOX + (size_t)RX_MAXR * 2 * RS_BMAX * 8;
+constexpr size_t RX_BYTES = RX_RBOX + (size_t)RX_MAXR * RX_RING * 16;
 __device__ __forceinline__ unsigned long long* rx_gbox(unsigned char* mb, int src, uint32_t par) { return reinterpret_cast<unsigned long long*>(mb + RX_GBOX) + ((size_t)src * 2 + par) * RS_BMAX; }
 __device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_RBOX) + (size_t)src * RX_RING * 2; }
 __device__ __forceinline__ unsigned long long rx_rtag(unsigned long long sweep, uint32_t batch) { return (0x80000000ull | ((sweep & 0x7ffull) << 20) | (unsigned long long)(batch & 0xfffffu)) << 32; }
@@ -291,7 +292,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     uint32_t* const pivl = reinterpret_cast<uint32_t*>(smem + 320);                    // [0] = number of the batch's pivots, [1 ..] their positions
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 97);  // [B][64 * T] codes of the window columns
     const bool timing = DBG && wg == 0 && tid == 0;
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = timing ? wall_clock64() : 0ull;
+    unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(smem + 384); // [8] stage clocks of the debug build (in LDS: sixteen registers less)
+    unsigned long long tmark = timing ? wall_clock64() : 0ull;
+    if (timing)
+        for (int i = 0; i < 8; ++i) tacc[i] = 0ull;
     auto lap = [&](int i) {
         if (timing) {
             const unsigned long long now = wall_clock64();
@@ -808,9 +812,9 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         unsigned long long tot;
         if (p.nranks > 1) { // this rank's part was taken by push_raw (same thread, same pass); the peers' parts: two self-validating words each
             const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
-            unsigned long long o[MAX_RANKS][2];
+            unsigned long long o[RX_MAXR][2];
 #pragma unroll
-            for (int r = 0; r < MAX_RANKS; ++r) {
+            for (int r = 0; r < RX_MAXR; ++r) {
                 const bool on = r < p.nranks && r != p.rank;
                 const unsigned long long* w = rx_rbox(p.mbox[p.rank], on ? r : p.rank) + 2u * (j % RX_RING);
                 o[r][0] = on ? __hip_atomic_load(w, HG_RLX_SYSTEM) : tag;
@@ -819,7 +823,7 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             bool all = true;
             tot = sh.rloc[slot];
 #pragma unroll
-            for (int r = 0; r < MAX_RANKS; ++r) {
+            for (int r = 0; r < RX_MAXR; ++r) {
                 all = all && (o[r][0] >> 32) == (tag >> 32) && (o[r][1] >> 32) == (tag >> 32);
                 tot += (o[r][1] << 32) | (o[r][0] & 0xffffffffull);
             }
@@ -958,14 +962,14 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
                         if (r != p.rank) __hip_atomic_store(rx_gbox(p.mbox[r], p.rank, par) + tid, tag | (unsigned long long)A, HG_RLX_SYSTEM);
                     const unsigned long long t0 = wall_clock64();
                     for (;;) {
-                        unsigned long long o[MAX_RANKS];
+                        unsigned long long o[RX_MAXR];
 #pragma unroll
-                        for (int r = 0; r < MAX_RANKS; ++r)
+                        for (int r = 0; r < RX_MAXR; ++r)
                             o[r] = (r < p.nranks && r != p.rank) ? __hip_atomic_load(rx_gbox(p.mbox[p.rank], r, par) + tid, HG_RLX_SYSTEM) : tag;
                         bool all = true;
                         uint32_t add = 0u;
 #pragma unroll
-                        for (int r = 0; r < MAX_RANKS; ++r) {
+                        for (int r = 0; r < RX_MAXR; ++r) {
                             all = all && (o[r] >> 24) == (tag >> 24);
                             add += (uint32_t)o[r] & RS_LOW;
                         }

@@ -1234,6 +1234,7 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
 {
     pl->ok = false;
     if (h->nranks > 1 && !(h->p2p_ready && h->p2p_enabled)) return "several ranks without peer mailboxes (hgibbs_p2p_import): the RCCL / host exchange lives in the batch engine";
+    if (h->nranks > RX_MAXR) return "more than eight ranks";
     if (h->force_split) return "force_split";
     if (h->any_missing) return "columns with missing calls";
     if (h->G * h->K > 256 || h->K > MAX_K || h->K < 2) return "mixture size";
@@ -1313,7 +1314,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.pivots = h->nranks > 1 ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange)
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
-    for (int r = 0; r < MAX_RANKS; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
+    for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
     p.sweep_id = ++h->res_sweep_id; // every rank runs the same sweeps on the resident engine (agreed in hgibbs_sweep): the counters stay equal
     p.trace = h->res_trace;
     p.progress = h->res_progress;
