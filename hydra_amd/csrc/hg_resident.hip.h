@@ -43,6 +43,8 @@ constexpr int RS_TRACE = 4096;            // messages whose stamps the debug bui
 constexpr int RS_TMAX = 2;                // most wave tiles per workgroup (16 T doubles of eps per lane, in every wave; a build for 4 spills registers)
 constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its arrival count in bits 24..31, the sum below
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
+constexpr unsigned long long RS_ONE64 = 1ull << 56; // build MISS: the same in an 8-byte word (the sum below is fixed point, units of 2^-RS_GFX)
+constexpr int RS_GFX = 32;                // a workgroup's four-term sum is < 2^15 (four terms of at most 4 * 2048 each): 47 bits, 55 over 255 workgroups
 constexpr int RX_MAXR = 8;                // ranks the engine shards over (one node of eight GPUs; more fall back to the batch engine): the walker keeps a load per peer in flight
 constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marker was an event (the walker wrote its component); cleared by k_res_finish
 
@@ -93,6 +95,9 @@ struct ResParams {
     uint32_t* gacc;           // [2][RS_NSH] rows of RS_GROW words, RS_BMAX in use: count << 24 | sum of the workgroups' Gram terms
     unsigned long long* racc; // [RS_RSH][RS_RB]: sum of the workgroups' raw dots (51-bit fixed point) of position p at p mod RS_RB
     uint32_t* rcnt;           // [RS_RSH] words RS_CROW apart: refill batches the shard's workgroups have completed
+    unsigned long long* racc2; // [RS_RSH][RS_RB] (build MISS): the same for R = sum of eps over the column's missing calls (s2 = sum of eps - R)
+    unsigned long long* gacc64; // [2][RS_NSH] rows of RS_GROW 8-byte words (build MISS): count << 56 | fixed-point sum of the workgroups' four-term Gram sums
+    const unsigned long long* counts; // [M][3] (n1, n2, missing) by marker, summed over the ranks
     uint32_t* pacc;           // [RS_RSH][RS_PMAX][RS_RB]: sum of the workgroups' Gram terms of position p (at p mod RS_RB) with its batch's pivots
     ResMsg* msg;              // [RS_MSG]
     ResState* state;
@@ -217,11 +222,19 @@ __device__ __forceinline__ void rs_set_read(uint32_t (&w)[T], const uint32_t (&k
 
 // per-lane values that travel with the sets (their loads must not make the compiler wait either): lane r keeps (mave, mstd) of set r's
 // column in v[216:217], v[218:219], its effect at sweep start in v[222:223] and the marker id of the set's NEXT column in v220 -- named registers as well
-__device__ __forceinline__ void rs_lane_load(const double* mave, const double* mstd, const double* bold, const int32_t* id)
+__device__ __forceinline__ void rs_lane_load(const double* mave, const double* mstd, const double* bold, const int32_t* id, const int32_t* ga)
 {
-    asm volatile("global_load_dwordx2 v[216:217], %0, off\n\tglobal_load_dwordx2 v[218:219], %1, off\n\tglobal_load_dwordx2 v[222:223], %2, off\n\tglobal_load_dword v220, %3, off" ::"v"(mave),
-                 "v"(mstd), "v"(bold), "v"(id)
-                 : "memory", "v216", "v217", "v218", "v219", "v220", "v222", "v223");
+    asm volatile("global_load_dwordx2 v[216:217], %0, off\n\tglobal_load_dwordx2 v[218:219], %1, off\n\tglobal_load_dwordx2 v[222:223], %2, off\n\tglobal_load_dword v220, %3, off\n\t"
+                 "global_load_dword v221, %4, off" ::"v"(mave),
+                 "v"(mstd), "v"(bold), "v"(id), "v"(ga)
+                 : "memory", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223");
+}
+// the columns' (group | flags) words: bit 29 = the column has missing calls
+__device__ __forceinline__ int32_t rs_lane_ga()
+{
+    int32_t v;
+    asm volatile("v_mov_b32 %0, v221" : "=v"(v));
+    return v;
 }
 __device__ __forceinline__ double2 rs_lane_meta()
 {
@@ -241,6 +254,24 @@ __device__ __forceinline__ int32_t rs_lane_ids()
 {
     int32_t v;
     asm volatile("v_mov_b32 %0, v220" : "=v"(v));
+    return v;
+}
+
+// 64-lane sum of a double on the DPP path, fixed order; the total is in lane 63 (rows that a step does not write add +0.0)
+__device__ __forceinline__ double rs_wave_sum_f64(double v)
+{
+    auto step = [&](auto ctrl, auto rmask) {
+        constexpr int C = decltype(ctrl)::value, RM = decltype(rmask)::value;
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, RM, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, RM, 0xF, false);
+        v += __hiloint2double(hi, lo);
+    };
+    step(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});  // quad_perm [1,0,3,2]
+    step(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});  // quad_perm [2,3,0,1]
+    step(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{}); // row_half_mirror
+    step(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{}); // row_mirror
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}); // row_bcast15
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}); // row_bcast31
     return v;
 }
 
@@ -275,7 +306,7 @@ __device__ __forceinline__ void fma_col(uint32_t g, const double (&e)[IPT], doub
     (fma_col4<Q>(g, e, a0, a1, a2, a3), ...);
 }
 
-template <int T, int DBG>
+template <int T, int DBG, int MISS>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
 {
     constexpr int RS_PF = 16; // register sets: columns one wave has in registers or on their way
@@ -342,7 +373,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         rs_set_load<T, r>(voff, p.bed + (size_t)(pn < M ? mk : 0) * p.stride);
     };
     // lane r < RS_PF: (mave, mstd) of the column of position p1 and the id of position p2
-    auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.s_bold + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u)); };
+    auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.s_bold + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u), p.s_ga + (p1 < M ? p1 : 0u)); };
     {
         // sets 0 .. RS_PF - 1 for k = 0 .. RS_PF - 1: the ids first (ordinary load), then the columns, then the lanes' values
         const uint32_t mp = pos_of((uint32_t)lane);
@@ -385,6 +416,53 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
             const uint32_t V = Sx - (q + 1u);
             const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
+            if constexpr (MISS) {
+            if (V && with_gram) {
+                // Four sums where a call may be missing in either column (x_j'x_q = mstd_j mstd_q (A - m_q B - m_j C + m_j m_q D), sums over
+                // the individuals called in both): with the missing calls' fields cleared, A = sum g_j g_q as before, B = G_j - P,
+                // C = G_q - Q, D = N - nm_j - nm_q + X with P = sum of g_j over q's missing calls, Q = sum of g_q over j's, X = calls
+                // missing in both -- popcounts against the missing masks.  What depends on the individuals, A + m_q P + m_j Q + m_j m_q X
+                // (>= 0), is summed over the wave as a double and sent as ONE fixed-point word per column (units of 2^-RS_GFX, arrival
+                // count in the top byte); the walker adds the rest from the markers' counts.
+                GramPivot gp[T];
+                uint32_t xqc[T], mq1[T], mq2[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    mq1[t] = xq[t] & (xq[t] >> 1) & 0x55555555u;
+                    mq2[t] = mq1[t] | (mq1[t] << 1);
+                    const uint32_t cq = xq[t] & ~mq2[t];
+                    gp[t] = gram_pivot(cq);
+                    xqc[t] = gram_xform(cq);
+                }
+                const double mqv = mq.x;
+                double mine = 0.0;
+                for (uint32_t c = 0; c < Vw; ++c) { // wave-uniform
+                    const uint32_t i = i0 + c;
+                    const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
+                    const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+                    const double mj = meta[slot].x;
+                    uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const uint32_t w = rp[t];
+                        const uint32_t mj1 = w & (w >> 1) & 0x55555555u, mj2 = mj1 | (mj1 << 1);
+                        const uint32_t xj = gram_xform(w & ~mj2);
+                        A += gram16x(xj, gp[t]);
+                        P += (uint32_t)__popc(xj & mq2[t]);
+                        Q += (uint32_t)__popc(xqc[t] & mj2);
+                        X += (uint32_t)__popc(mj1 & mq1[t]);
+                    }
+                    const double cv = ((double)A + mqv * (double)P) + (mj * (double)Q + (mj * mqv) * (double)X);
+                    const double tot = rs_readlane(rs_wave_sum_f64(cv), 63);
+                    mine = (uint32_t)lane == c ? tot : mine;
+                }
+                if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
+                    const double MAGIC = 6755399441055744.0;
+                    const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
+                    __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE64 | fx, HG_RLX_AGENT);
+                }
+            }
+            } else
             if (V && with_gram) {
             GramPivot gp[T];
 #pragma unroll
@@ -436,6 +514,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (done_m) cols_landed(); // a second pass in one round (more than 8 RS_PF new columns): its columns are asked for here and now
             const uint32_t m = count_w < (uint32_t)RS_PF ? count_w : (uint32_t)RS_PF; // register sets in use this pass: k in [nk, nk + m)
             const int32_t ids = rs_lane_ids(); // lane r: marker id of set r's next column
+            const int32_t gal = MISS ? rs_lane_ga() : 0; // lane r: (group | flags) of set r's column
             // one register set = one column: no arithmetic is spent on a set that is not this pass's (the sets in use are a circular
             // run of m of the 16: taken four at a time, a quarter of the work was for columns not asked for -- and waves with one quad
             // more than the others kept the workgroup's barrier waiting)
@@ -446,13 +525,37 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     double a[4] = {0.0, 0.0, 0.0, 0.0};
                     uint32_t gw[T];
                     rs_set_read<T, r>(gw, keep);
-#pragma unroll
-                    for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
                     const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr));
                     const uint32_t slot = pos & bmask;
                     uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) rp[t] = gw[t];
+                    for (int t = 0; t < T; ++t) rp[t] = gw[t]; // (the codes as they are: the update's table gives a missing call the addend 0)
+                    if constexpr (MISS) {
+                        // a column with missing calls (:1785-1790): s1 over the calls that are there -- the missing ones' fields are cleared,
+                        // weight 0 -- and R = sum of eps over the missing ones (s2 = sum of eps - R), the same three instructions per
+                        // individual on the 1-bit field; both summed over the whole wave here (the LDS that would hold eight partial sums
+                        // of each is the window's)
+                        double rr[4] = {0.0, 0.0, 0.0, 0.0};
+                        if (__builtin_amdgcn_readlane(gal, r) & 0x20000000) { // wave-uniform
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                const uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
+                                fma_col(gw[t] & ~(mm | (mm << 1)), e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                                fma_col(mm, e[t], rr[0], rr[1], rr[2], rr[3], std::make_integer_sequence<int, IPT / 4>{});
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                        }
+                        const double v = rs_wave_sum_f64((a[0] + a[1]) + (a[2] + a[3]));
+                        const double w = rs_wave_sum_f64((rr[0] + rr[1]) + (rr[2] + rr[3]));
+                        if (lane == 63) {
+                            part[(pos - Sx) * 2u] = v;
+                            part[(pos - Sx) * 2u + 1u] = w;
+                        }
+                    } else {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
                     // the lane sums meet in eight-lane groups (three DPP steps, fixed order); the eight group sums go to LDS and
                     // are added by ONE thread per column behind the barrier (in order: the dot does not depend on which wave took it)
                     double v = (a[0] + a[1]) + (a[2] + a[3]);
@@ -460,6 +563,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     v += rs_dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
                     v += rs_dpp_f64<0x141>(v); // row_half_mirror
                     if ((lane & 7) == 0) part[(pos - Sx) * 8u + ((uint32_t)lane >> 3)] = v;
+                    }
                     // the consumed set takes its next column now: the load leaves HBM while the other sets are at work (no wait is
                     // triggered by it: it is waited for by hand, at the top of the next round)
                     if (!last) load_set(rtag, kr + (uint32_t)RS_PF, ids);
@@ -532,13 +636,22 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         // the order of arrival.  Once the adds have been performed, one add to the shard's batch counter tells the walker that this
         // workgroup's part is in.
         for (uint32_t t = (uint32_t)tid; t < nnew; t += RS_BLOCK) {
-            const double* pp = part + t * 8u;
-            double s1 = pp[0];
+            const double MAGIC = 6755399441055744.0;
+            double s1;
+            if constexpr (MISS) {
+                s1 = part[t * 2u];
+                const double xr = part[t * 2u + 1u] * p.fx_scale;
+                if (!(fabs(xr) < 2.2e15)) atomicMax(&p.state->error, 5u);
+                const long long fr = __double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC);
+                __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr, HG_RLX_AGENT);
+            } else {
+                const double* pp = part + t * 8u;
+                s1 = pp[0];
 #pragma unroll
-            for (int i = 1; i < 8; ++i) s1 += pp[i];
+                for (int i = 1; i < 8; ++i) s1 += pp[i];
+            }
             const double xs = s1 * p.fx_scale;
             if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
-            const double MAGIC = 6755399441055744.0;
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
             const uint32_t np = pivl[0];
@@ -628,6 +741,9 @@ struct WalkShared {
     uint8_t* ekq;     // [B] its component
     uint8_t* ada;
     uint8_t* fdone; // the slot's raw dot has arrived
+    double *gsum, *nmis;       // [B] build MISS: the column's sum of genotypes n1 + 2 n2 and its number of missing calls (all ranks)
+    unsigned long long* rprev2; // [RS_RB] build MISS: rprev for the sums over the missing calls
+    unsigned long long* gpart64; // [RS_NSH][RS_BMAX] build MISS: gpart for the 8-byte words
     unsigned long long* rloc; // [B] several ranks: this rank's part of the slot's raw dot (pushed to the peers; the dot needs theirs)
     uint8_t* fpush;           // [B] ... has been taken and pushed
     unsigned char* end;
@@ -656,6 +772,10 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.pf_val = reinterpret_cast<double*>(q); q += (size_t)RS_PFIRE * 3 * 8;
     s.ebn = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.rloc = reinterpret_cast<unsigned long long*>(q); q += (size_t)B * 8;
+    s.gsum = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.nmis = reinterpret_cast<double*>(q); q += (size_t)B * 8;
+    s.rprev2 = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
+    s.gpart64 = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_NSH * RS_BMAX * 8;
     s.tq = reinterpret_cast<double*>(q); q += (size_t)MT_BUF * 8;
     s.qtab = reinterpret_cast<double*>(q); q += (size_t)2 * HT_LDS * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
@@ -682,8 +802,10 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
 // bytes of LDS the walker needs: the end of its own carve-up (so that the two cannot disagree)
 __host__ __device__ inline size_t rs_walker_lds(uint32_t B) { return (size_t)(walk_carve(nullptr, B).end - (unsigned char*)nullptr) + 64; }
 
-template <int DBG>
-__device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* smem)
+// (a function of its own, not inlined: the kernel's body is then the streaming workgroup alone -- what the register budget of the
+// landing registers is about, and what tools/asm_check_loads.py checks; the walker may use every register)
+template <int DBG, int MISS>
+__device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigned char* smem)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t B = p.B, bmask = B - 1u, M = p.M;
@@ -691,7 +813,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     const bool lds_tab = p.GK <= HT_LDS;
     const WalkShared sh = walk_carve(smem, B);
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = wall_clock64();
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = DBG ? wall_clock64() : 0ull;
+    unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(sh.fd + 32); // [8] stage clocks of the debug build (in LDS: sixteen registers less)
+    unsigned long long tmark = DBG ? wall_clock64() : 0ull;
+    if (DBG && tid == 0)
+        for (int i = 0; i < 8; ++i) tacc[i] = 0ull;
     auto lap = [&](int i) {
         if (DBG && tid == 0) {
             const unsigned long long now = wall_clock64();
@@ -724,7 +849,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.qtab[i] = (p.logpi[i] - p.hlog[i]) - p.logpi[g0];
             sh.qtab[HT_LDS + i] = (i % K) ? p.i_2sigE / p.denom[i] : 0.0;
         }
-    for (int i = tid; i < RS_RB; i += RS_BLOCK) sh.rprev[i] = 0ull;
+    for (int i = tid; i < RS_RB; i += RS_BLOCK) {
+        sh.rprev[i] = 0ull;
+        sh.rprev2[i] = 0ull;
+    }
     for (int i = tid; i < RS_PMAX * RS_RB; i += RS_BLOCK) sh.pprev[i] = 0u;
     if (tid < 64) sh.fl[tid] = 0u;
     auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
@@ -743,6 +871,11 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.bold[slot] = p.s_bold[j];
             sh.mave[slot] = p.s_mave[j];
             sh.mstd[slot] = p.s_mstd[j];
+            if constexpr (MISS) {
+                const unsigned long long* cn = p.counts + 3ull * (unsigned long long)p.order[j];
+                sh.gsum[slot] = (double)(cn[0] + 2ull * cn[1]);
+                sh.nmis[slot] = (double)cn[2];
+            }
             sh.dp[slot] = 0.0;
             sh.fdone[slot] = 0;
             sh.fpush[slot] = 0;
@@ -759,7 +892,8 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
     bool has_next = false, aborted = false;
     bool pendG = false;
     uint32_t gq = 0, gV = 0;          // the event whose Gram terms are still to be collected: position, window columns behind it
-    double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0;
+    double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0, g_gsum = 0.0, g_nmis = 0.0;
+    unsigned long long gprev64[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}}; // build MISS: the lane's four 8-byte words as last seen, per parity
     unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0;
     // the pivots of refill batch `batch`: the first RS_PMAX positions of the window [lo, hi) -- as it stands when the batch is streamed --
     // whose marker has a non-zero effect at sweep start (the streaming workgroups find the same list: res_streamer)
@@ -843,7 +977,20 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             sh.rprev[j % RS_RB] = now;
         }
         const double s1 = (double)(long long)tot * p.fx_unscale;
-        sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * p.eps_sum);
+        double s2 = p.eps_sum;
+        if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R (single rank: resident_plan)
+            unsigned long long* base2 = p.racc2 + (j % RS_RB);
+            unsigned long long w2[RS_RSH];
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) w2[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base2 + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
+            unsigned long long now2 = 0ull;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
+            const unsigned long long tot2 = now2 - sh.rprev2[j % RS_RB];
+            sh.rprev2[j % RS_RB] = now2;
+            s2 -= (double)(long long)tot2 * p.fx_unscale;
+        }
+        sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * s2);
         // the column's Gram terms with its batch's pivots (those in front of it), and the corrections of the pivots that have fired since
         // the column was streamed
         const uint32_t bt = sh.batch[slot], np = sh.bl_np[bt % RS_NB];
@@ -916,7 +1063,53 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
         }
         // 1. Gram terms of the window columns behind the last event (the streaming workgroups' first job after a message): wave s
         // polls shard s's row, 16 bytes per lane; every word in use must carry the shard's full arrival count
-        if (pendG && gV) {
+        if (MISS && pendG && gV) {
+            // the same with 8-byte words (four per lane, two loads): count in the top byte, below it the fixed-point sum of the
+            // workgroups' four-term sums; the terms that do not depend on the individuals come from the markers' counts
+            const int ws = tid >> 6;
+            const uint32_t par = (nev - 1u) & 1u;
+            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < gV) {
+                const unsigned long long* row = p.gacc64 + ((size_t)par * RS_NSH + (uint32_t)ws) * RS_GROW + 4u * (uint32_t)lane;
+                const unsigned long long want = cntG[0 + ((uint32_t)ws < p.W % p.nsh ? 0 : 1)];
+                const unsigned long long t0 = wall_clock64();
+                unsigned long long v[4], d[4];
+                for (;;) {
+                    const u4_t a = rs_load16(row), b = rs_load16(row + 2);
+                    v[0] = ((unsigned long long)a.y << 32) | a.x;
+                    v[1] = ((unsigned long long)a.w << 32) | a.z;
+                    v[2] = ((unsigned long long)b.y << 32) | b.x;
+                    v[3] = ((unsigned long long)b.w << 32) | b.z;
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        d[i] = v[i] - gprev64[par][i];
+                        ok = ok && (4u * (uint32_t)lane + (uint32_t)i >= gV || (d[i] >> 56) == want);
+                    }
+                    if (ok) break;
+                    if (wall_clock64() - t0 > p.timeout) {
+                        sh.fl[WF_ABORT] = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    gprev64[par][i] = v[i];
+                    sh.gpart64[(uint32_t)ws * RS_BMAX + 4u * (uint32_t)lane + (uint32_t)i] = d[i] & (RS_ONE64 - 1ull);
+                }
+            }
+            __syncthreads();
+            if ((uint32_t)tid < gV) {
+                unsigned long long A = 0ull;
+                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart64[sidx * RS_BMAX + (uint32_t)tid];
+                const uint32_t slot = (gq + 1u + (uint32_t)tid) & bmask;
+                const double mj = sh.mave[slot], sj = sh.mstd[slot];
+                const double Ad = (double)A * (1.0 / (double)(1ull << RS_GFX));
+                const double both = p.n_total - sh.nmis[slot] - g_nmis; // + X: calls present in both columns
+                const double xx = sj * g_mstd * (((Ad - g_mave * sh.gsum[slot]) - mj * g_gsum) + (mj * g_mave) * both);
+                sh.dp[slot] += g_db * xx;
+            }
+        } else if (pendG && gV) {
             const int ws = tid >> 6;
             const uint32_t par = (nev - 1u) & 1u;
             if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < gV) {
@@ -1268,6 +1461,10 @@ __device__ __forceinline__ void res_walker(const ResParams& p, unsigned char* sm
             g_db = dbeta;
             g_mave = sh.mave[slot];
             g_mstd = sh.mstd[slot];
+            if constexpr (MISS) {
+                g_gsum = sh.gsum[slot];
+                g_nmis = sh.nmis[slot];
+            }
             ++nev;
             ++n_events;
             ++n_nnz;
@@ -1419,11 +1616,11 @@ __global__ __launch_bounds__(256) void k_res_finish(ResParams p)
         if (lc[i]) atomicAdd(p.cass + i, lc[i]);
 }
 
-template <int T, int DBG>
-__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p)
+template <int T, int DBG, int MISS>
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p, const ResParams* pg)
 {
-    if (blockIdx.x < p.W) res_streamer<T, DBG>(p, hg_smem);
-    else res_walker<DBG>(p, hg_smem);
+    if (blockIdx.x < p.W) res_streamer<T, DBG, MISS>(p, hg_smem);
+    else res_walker<DBG, MISS>(*pg, hg_smem); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
 }
 
 } // namespace hg

@@ -155,6 +155,8 @@ struct hgibbs_ctx {
     ResMsg* res_msg = nullptr;
     ResState* res_state = nullptr;
     ResState* res_state_host = nullptr; // pinned
+    ResParams* res_params = nullptr;      // the sweep's parameters in device memory (the walker reads them there) and their pinned staging copy
+    ResParams* res_params_host = nullptr;
     unsigned long long* res_progress = nullptr; // device, written by the kernel while it runs
     unsigned long long* res_progress_host = nullptr; // pinned copy, fetched on a second stream when the host's deadline passes
     hipStream_t aux_stream = nullptr;
@@ -175,7 +177,8 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
 }
 
 static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4, RES_PACC_BYTES = (size_t)RS_RSH * RS_PMAX * RS_RB * 4;
-static constexpr size_t RES_ACC_BYTES = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES + RES_PACC_BYTES;
+static constexpr size_t RES_RACC2_OFF = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES + RES_PACC_BYTES, RES_GACC64_BYTES = (size_t)2 * RS_NSH * RS_GROW * 8;
+static constexpr size_t RES_ACC_BYTES = RES_RACC2_OFF + RES_RACC_BYTES + RES_GACC64_BYTES; // (+ the MISS build's second raw sums and its 8-byte Gram words)
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
 static constexpr size_t MBOX_BATCH_BYTES = MBOX_DATA_BYTES + (size_t)2 * MAX_RANKS * sizeof(unsigned long long); // the batch engine's rows and flags
 static constexpr size_t MBOX_RES_OFF = (MBOX_BATCH_BYTES + 4095) / 4096 * 4096;                                  // behind them the resident engine's mailbox (hg_resident.hip.h, RX_*)
@@ -579,6 +582,8 @@ int hgibbs_create(int device_id, hgibbs_t* out)
     HIP_TRY(hipMalloc(&h->res_msg, RS_MSG * sizeof(ResMsg)));
     HIP_TRY(hipMalloc(&h->res_state, sizeof(ResState)));
     HIP_TRY(hipHostMalloc(&h->res_state_host, sizeof(ResState)));
+    HIP_TRY(hipMalloc(&h->res_params, sizeof(ResParams)));
+    HIP_TRY(hipHostMalloc(&h->res_params_host, sizeof(ResParams)));
     HIP_TRY(hipMalloc(&h->res_progress, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&h->res_progress_host, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
@@ -605,6 +610,8 @@ int hgibbs_destroy(hgibbs_t h)
     if (h->desc_host) (void)hipHostFree(h->desc_host);
     if (h->scratch_host) (void)hipHostFree(h->scratch_host);
     if (h->res_state_host) (void)hipHostFree(h->res_state_host);
+    if (h->res_params) (void)hipFree(h->res_params);
+    if (h->res_params_host) (void)hipHostFree(h->res_params_host);
     if (h->res_progress) (void)hipFree(h->res_progress);
     if (h->res_progress_host) (void)hipHostFree(h->res_progress_host);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -1236,7 +1243,7 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     if (h->nranks > 1 && !(h->p2p_ready && h->p2p_enabled)) return "several ranks without peer mailboxes (hgibbs_p2p_import): the RCCL / host exchange lives in the batch engine";
     if (h->nranks > RX_MAXR) return "more than eight ranks";
     if (h->force_split) return "force_split";
-    if (h->any_missing) return "columns with missing calls";
+    if (h->any_missing && h->nranks > 1) return "columns with missing calls on several ranks (their four-term Gram sums have no cross-rank exchange)";
     if (h->G * h->K > 256 || h->K > MAX_K || h->K < 2) return "mixture size";
     const uint32_t cus = h->res_cus ? std::min<uint32_t>(h->res_cus, (uint32_t)h->num_cu) : (uint32_t)h->num_cu;
     if (cus < 2) return "fewer than two compute units";
@@ -1294,6 +1301,9 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.racc = reinterpret_cast<unsigned long long*>(h->res_acc + RES_GACC_BYTES);
     p.rcnt = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES);
     p.pacc = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES);
+    p.racc2 = reinterpret_cast<unsigned long long*>(h->res_acc + RES_RACC2_OFF);
+    p.gacc64 = reinterpret_cast<unsigned long long*>(h->res_acc + RES_RACC2_OFF + RES_RACC_BYTES);
+    p.counts = h->counts;
     p.msg = h->res_msg;
     p.state = h->res_state;
     {
@@ -1311,7 +1321,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     }
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.dbg = h->debug_timing ? 1 : 0;
-    p.pivots = h->nranks > 1 ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange)
+    p.pivots = (h->nranks > 1 || h->any_missing) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
@@ -1324,14 +1334,15 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
     const size_t lds = std::max(rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
-    void (*kern)(ResParams) = nullptr;
+    void (*kern)(ResParams, const ResParams*) = nullptr;
     const bool dbg = h->debug_timing;
+    const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
     switch (pl.T) {
-    case 1: kern = dbg ? k_sweep_resident<1, 1> : k_sweep_resident<1, 0>; break;
-    default: kern = dbg ? k_sweep_resident<2, 1> : k_sweep_resident<2, 0>; break;
+    case 1: kern = miss ? (dbg ? k_sweep_resident<1, 1, 1> : k_sweep_resident<1, 0, 1>) : (dbg ? k_sweep_resident<1, 1, 0> : k_sweep_resident<1, 0, 0>); break;
+    default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
     }
     static bool attr_set[8] = {};
-    const int ai = (pl.T == 1 ? 0 : (pl.T == 2 ? 1 : 2)) * 2 + (dbg ? 1 : 0);
+    const int ai = (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
     if (!attr_set[ai]) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ai] = true;
@@ -1346,7 +1357,9 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     if (std::getenv("HGIBBS_DEBUG"))
         std::fprintf(stderr, "[hgibbs] resident sweep: T %d, %u streaming workgroups, window %u, LDS %zu B, fixed-point scale 2^%d\n", pl.T, pl.W, pl.B, lds, (int)std::log2(p.fx_scale));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p);
+    *h->res_params_host = p;
+    HIP_TRY(hipMemcpyAsync(h->res_params, h->res_params_host, sizeof(ResParams), hipMemcpyHostToDevice, h->stream));
+    kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p, h->res_params);
     HIP_TRY(hipGetLastError());
     k_res_finish<<<dim3((h->M + 255u) / 256u), 256, 0, h->stream>>>(p); // numerators -> Acum, components and cass of the markers that were no event
     HIP_TRY(hipGetLastError());

@@ -15,14 +15,20 @@ from test_gpu_parity import close, _same_stream
 pytestmark = pytest.mark.gpu
 
 
-def make_case(M, N, seed=7, causal_frac=0.05):
+def make_case(M, N, seed=7, causal_frac=0.05, missing_rate=0.0, missing_cols=1.0):
     geno = synth.make_genotypes(M, N, seed=seed, missing_rate=0.0)
+    if missing_rate > 0.0:  # missing calls in a share of the columns (the others take the plain path inside the same build)
+        rng = np.random.default_rng(seed + 17)
+        for c in np.flatnonzero(rng.random(M) < missing_cols):
+            geno[c, rng.random(N) < missing_rate] = 3
+            if len(np.unique(geno[c][geno[c] != 3])) < 2:  # (no monomorphic marker: division by zero in the reference too)
+                geno[c, :3] = (0, 1, 2)
     y, _ = synth.make_phenotype(geno, seed=seed + 1, h2=0.5, causal_frac=causal_frac)
     return synth.pack_bed_columns(geno), y
 
 
-def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None):
-    bed, y = make_case(M, N, seed=M + N, causal_frac=causal_frac)
+def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None, missing_rate=0.0, missing_cols=1.0):
+    bed, y = make_case(M, N, seed=M + N, causal_frac=causal_frac, missing_rate=missing_rate, missing_cols=missing_cols)
     ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
     dev = capi.Device(0)
     dev.load_bed(bed, N)
@@ -156,12 +162,29 @@ def test_predicted_pivots_many_workgroups(oracle):
     assert dev.sweep_stats()["pivots"] > 0
 
 
+@pytest.mark.parametrize("N,rate,cols", [(1024, 0.02, 1.0), (4099, 0.01, 1.0), (9001, 0.05, 0.3), (20011, 0.01, 1.0)])
+def test_missing_calls(oracle, N, rate, cols):
+    """Columns with missing calls (the build that keeps s2 = sum of eps over a column's calls per column and takes the four-term
+    Gram sums A, B, C, D of src/BayesRRm.cpp:1785-1790's algebra): in every column, or in a share of them next to clean ones."""
+    run_vs_oracle(oracle, 400, N, iters=4, missing_rate=rate, missing_cols=cols)
+
+
+def test_missing_calls_small_window_and_two_tiles(oracle):
+    run_vs_oracle(oracle, 400, 8000, iters=3, missing_rate=0.03, opts={"window": 16, "res_cus": 5}, expect_T=2)
+
+
+def test_missing_calls_heavy(oracle):
+    # a fifth of all calls missing: the sparse terms P, Q, X are as large as they get against A
+    run_vs_oracle(oracle, 300, 3000, iters=3, missing_rate=0.2, causal_frac=0.2)
+
+
 def test_refused_where_it_does_not_apply(oracle):
-    geno = synth.make_genotypes(50, 500, seed=1, missing_rate=0.05)
+    geno = synth.make_genotypes(50, 6000, seed=1, missing_rate=0.0)
     y, _ = synth.make_phenotype(geno, seed=2)
     dev = capi.Device(0)
-    dev.load_bed(synth.pack_bed_columns(geno), 500)
+    dev.load_bed(synth.pack_bed_columns(geno), 6000)
     dev.set_option("engine", 2)
+    dev.set_option("res_cus", 2)  # one streaming workgroup: six wave tiles are more than it holds in registers
     ch = capi.Chain(dev, y, seed=1)
     with pytest.raises(capi.HgError, match="resident engine does not apply"):
         ch.iterate()

@@ -1,5 +1,5 @@
 """Where a round of the resident sweep engine spends its time (option debug_timing: 100 MHz stage clocks of the walker
-and of streaming workgroup 0, accumulated over a sweep).  usage: res_anatomy.py [N M [iters [name=value ...]]]"""
+and of streaming workgroup 0, accumulated over a sweep).  usage: res_anatomy.py [N M [iters [name=value ... | missing=rate | timing=0/1]]]"""
 import os
 import sys
 import time
@@ -16,13 +16,16 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = capi.Device(0)
 dev.set_option("engine", 2)
 timing = 1
+missing = 0.0
 for kv in sys.argv[4:]:
     k, _, v = kv.partition("=")
     if k == "timing":
         timing = int(v)
+    elif k == "missing":
+        missing = float(v)
     else:
         dev.set_option(k, int(v))
-dev.synth_bed(N, M, seed=42, missing_rate=0.0, row_begin=0, row_end=N)
+dev.synth_bed(N, M, seed=42, missing_rate=missing, row_begin=0, row_end=N)
 y = bench.make_phenotype_on_device(dev, N, M, (0, N), seed=43, causal_frac=0.01)
 ch = capi.Chain(dev, y, seed=1222, shuffle=1)
 for it in range(iters):
