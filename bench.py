@@ -579,6 +579,12 @@ def main():
             roof["markers_per_round"] = accepted / max(1, rounds)
             roof["events_per_iter"] = sum(s["events"] for s, _ in stats) / K
             roof["advances_per_iter"] = sum(s["advances"] for s, _ in stats) / K
+            # census of why rounds end: an event at a marker whose effect was non-zero at sweep start (certain to change), an event
+            # that came unannounced, or the window ran out (advance); rounds whose walk had to wait for dots still on their way
+            roof["census_per_iter"] = {"predicted_events": sum(s["predicted"] for s, _ in stats) / K,
+                                       "unannounced_events": sum(s["events"] - s["predicted"] for s, _ in stats) / K,
+                                       "window_ran_out": sum(s["advances"] for s, _ in stats) / K,
+                                       "walks_that_waited_for_dots": sum(s["refolds"] for s, _ in stats) / K}
             roof["eps_sum_drift_max"] = max(s["eps_sum_drift"] for s, _ in stats)
             if anatomy:
                 roof["anatomy_us"] = anatomy

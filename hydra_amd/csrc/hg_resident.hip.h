@@ -59,7 +59,7 @@ struct ResMsg {
 
 struct ResState { // device -> host, written by the walker at the end of the sweep
     uint32_t cursor, rng_idx, error, pad;
-    unsigned long long rounds, events, advances, nnz, chunks, refolds, pivots;
+    unsigned long long rounds, events, advances, nnz, chunks, refolds, pivots, predicted;
     unsigned long long shader_ticks, wall_ticks; // s_memtime and 100 MHz wall clock over the walker's life: the clock the chip held
     unsigned long long t[16]; // 100 MHz ticks: walker [0] fold [1] collect [2] evaluate [3] scan + draw [4] announce + outputs + prefetch;
                               // streaming workgroup 0: [8] poll [9] update [10] Gram [11] refill dots [12] barrier [13] raw atomics + drain [14] barrier + count [15] prefetch issue
@@ -275,6 +275,13 @@ __device__ __forceinline__ double rs_wave_sum_f64(double v)
     return v;
 }
 
+// A pivot's masks from its x form (hg_sweep.hip.h: u = [g >= 1] in the even bit, v = [g == 2] in the odd one)
+__device__ __forceinline__ GramPivot gram_pivot_x(uint32_t x)
+{
+    const uint32_t ue = x & 0x55555555u, vo = x & 0xAAAAAAAAu;
+    return GramPivot{ue | (ue << 1), vo | (vo >> 1)};
+}
+
 // The dot product's inner step for ONE column: four slots S .. S + 3 of a dword into four accumulators (field extract, int -> f64,
 // fused multiply-add, issued as three groups of four: three independent instructions between a producer and its consumer).
 // a_i += double((g >> 2 (4 Q + i)) & 3) * e[4 Q + i] -- the products are exact, one rounding per add.
@@ -403,7 +410,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (tid < 16) {
                 const double av = mq.x, sd = mq.y, db = dbeta;
                 const double v0 = -(av * sd * db), v1 = db * (1.0 - av) * sd, v2 = db * (2.0 - av) * sd;
-                auto addend = [&](uint32_t c) { return 0.0 + ((c == GC_G0) ? v0 : ((c == GC_G1) ? v1 : ((c == GC_G2) ? v2 : 0.0))); };
+                // (window codes: the x form 00 / 01 / 11 = genotype 0 / 1 / 2; build MISS: the device codes, 11 = missing call, addend 0)
+                auto addend = [&](uint32_t c) { return 0.0 + ((c == 0u) ? v0 : ((c == 1u) ? v1 : ((c == (MISS ? 2u : 3u)) ? v2 : 0.0))); };
                 tab[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
             }
             __syncthreads();
@@ -436,25 +444,34 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 }
                 const double mqv = mq.x;
                 double mine = 0.0;
-                for (uint32_t c = 0; c < Vw; ++c) { // wave-uniform
-                    const uint32_t i = i0 + c;
-                    const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
-                    const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-                    const double mj = meta[slot].x;
-                    uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
+                for (uint32_t c0 = 0; c0 < Vw; c0 += 4u) { // wave-uniform; four columns at a time: their wave sums are four independent chains
+                    double cv[4];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const uint32_t w = rp[t];
-                        const uint32_t mj1 = w & (w >> 1) & 0x55555555u, mj2 = mj1 | (mj1 << 1);
-                        const uint32_t xj = gram_xform(w & ~mj2);
-                        A += gram16x(xj, gp[t]);
-                        P += (uint32_t)__popc(xj & mq2[t]);
-                        Q += (uint32_t)__popc(xqc[t] & mj2);
-                        X += (uint32_t)__popc(mj1 & mq1[t]);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t i = i0 + c0 + (uint32_t)k;
+                        const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
+                        const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+                        const double mj = meta[slot].x;
+                        uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) {
+                            const uint32_t w = rp[t];
+                            const uint32_t mj1 = w & (w >> 1) & 0x55555555u, mj2 = mj1 | (mj1 << 1);
+                            const uint32_t xj = gram_xform(w & ~mj2);
+                            A += gram16x(xj, gp[t]);
+                            P += (uint32_t)__popc(xj & mq2[t]);
+                            Q += (uint32_t)__popc(xqc[t] & mj2);
+                            X += (uint32_t)__popc(mj1 & mq1[t]);
+                        }
+                        cv[k] = ((double)A + mqv * (double)P) + (mj * (double)Q + (mj * mqv) * (double)X);
                     }
-                    const double cv = ((double)A + mqv * (double)P) + (mj * (double)Q + (mj * mqv) * (double)X);
-                    const double tot = rs_readlane(rs_wave_sum_f64(cv), 63);
-                    mine = (uint32_t)lane == c ? tot : mine;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cv[k] = rs_wave_sum_f64(cv[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double tot = rs_readlane(cv[k], 63);
+                        mine = (uint32_t)lane == c0 + (uint32_t)k ? tot : mine;
+                    }
                 }
                 if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
                     const double MAGIC = 6755399441055744.0;
@@ -466,7 +483,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (V && with_gram) {
             GramPivot gp[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) gp[t] = gram_pivot(xq[t]);
+            for (int t = 0; t < T; ++t) gp[t] = gram_pivot_x(xq[t]);
             uint32_t acc[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0u;
@@ -486,7 +503,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     for (int c = 0; c < 8; ++c) {
                         uint32_t g = 0u;
 #pragma unroll
-                        for (int t = 0; t < T; ++t) g += gram16x(gram_xform(wv[c][t]), gp[t]);
+                        for (int t = 0; t < T; ++t) g += gram16x(wv[c][t], gp[t]);
                         acc[(cb + c) >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
                     }
                 }
@@ -529,7 +546,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     const uint32_t slot = pos & bmask;
                     uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) rp[t] = gw[t]; // (the codes as they are: the update's table gives a missing call the addend 0)
+                    for (int t = 0; t < T; ++t) rp[t] = MISS ? gw[t] : gram_xform(gw[t]); // the window keeps the x form (00, 01, 11 for genotype 0, 1, 2): what the Gram terms of
+                                                                                          // EVERY later event need, made once; with missing calls the codes as they are (11 = missing)
                     if constexpr (MISS) {
                         // a column with missing calls (:1785-1790): s1 over the calls that are there -- the missing ones' fields are cleared,
                         // weight 0 -- and R = sum of eps over the missing ones (s2 = sum of eps - R), the same three instructions per
@@ -615,7 +633,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 {
                     const uint32_t* rp = ring + (pv & bmask) * 64u * T + (uint32_t)lane * T;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) gq[t] = gram_pivot(rp[t]);
+                    for (int t = 0; t < T; ++t) gq[t] = gram_pivot_x(rp[t]);
                 }
                 for (uint32_t k = round_k0; k < nk; ++k) {
                     const uint32_t pos = pos_of(k);
@@ -623,7 +641,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     const uint32_t* rp = ring + (pos & bmask) * 64u * T + (uint32_t)lane * T;
                     uint32_t g = 0u;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) g += gram16x(gram_xform(rp[t]), gq[t]);
+                    for (int t = 0; t < T; ++t) g += gram16x(rp[t], gq[t]);
                     const uint32_t tot = wave_sum_u32(g);
                     if (lane == 0) pterm[(pos - Sx) * (uint32_t)RS_PMAX + ip] = tot;
                 }
@@ -894,7 +912,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
     uint32_t gq = 0, gV = 0;          // the event whose Gram terms are still to be collected: position, window columns behind it
     double g_db = 0.0, g_mave = 0.0, g_mstd = 0.0, g_gsum = 0.0, g_nmis = 0.0;
     unsigned long long gprev64[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}}; // build MISS: the lane's four 8-byte words as last seen, per parity
-    unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0;
+    unsigned long long n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0, n_pred = 0;
     // the pivots of refill batch `batch`: the first RS_PMAX positions of the window [lo, hi) -- as it stands when the batch is streamed --
     // whose marker has a non-zero effect at sweep start (the streaming workgroups find the same list: res_streamer)
     auto batch_pivots = [&](uint32_t batch, uint32_t lo, uint32_t hi) {
@@ -1375,6 +1393,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         const double dbeta = found ? sh.fd[WD_DBETA] : 0.0, bnew = found ? sh.fd[WD_BNEW] : 0.0;
         const int kq = found ? (int)sh.fl[WF_K] : 0;
         const bool is_event = found && dbeta != 0.0;
+        if (is_event && sh.bold[qpos & bmask] != 0.0) ++n_pred;
         const uint32_t Cn = C + ncons;
         const bool lastmsg = Cn >= M;
         // A predicted pivot whose Gram terms came with the columns: every refill batch that has columns behind it in the window must
@@ -1563,6 +1582,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         st->chunks = n_chunks;
         st->refolds = n_refold;
         st->pivots = n_pivots;
+        st->predicted = n_pred;
         st->shader_ticks = __builtin_amdgcn_s_memtime() - clk0;
         st->wall_ticks = wall_clock64() - wall0;
         if (DBG)

@@ -1414,6 +1414,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.chunks = st.chunks;
     s.refolds = st.refolds;
     s.pivots = st.pivots;
+    s.predicted = st.predicted;
     for (int i = 0; i < 16; ++i) s.ticks[i] = st.t[i];
     s.shader_mhz = st.wall_ticks ? 100.0 * (double)st.shader_ticks / (double)st.wall_ticks : 0.0;
     {

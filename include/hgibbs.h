@@ -143,7 +143,18 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
                  uint64_t* nnz_updates);
 
 /* Tuning knobs of the sweep (not part of the reference's behaviour; every setting gives the same chain up to
- * floating-point rounding, and bit-identical chains with gram = 0).  0 = automatic where noted.
+ * floating-point rounding, and bit-identical chains on the batch engine with gram = 0).  0 = automatic where noted.
+ *   engine          0 auto (default): the resident engine where it applies, else the batch engine; 1 batch engine (one launch
+ *                   per batch of markers up to an event); 2 resident engine (ONE launch per sweep; the call fails where it does
+ *                   not apply: several ranks without peer mailboxes or more than eight, missing calls on several ranks, a
+ *                   shard of more than 2048 individuals per compute unit, G * K > 256).  Setting any option of the batch
+ *                   engine below (a batch width, ...) while engine = 0 selects the batch engine.
+ *   window          resident engine: columns kept in LDS behind the cursor, a power of two <= 256 (0 auto: 256)
+ *   res_cus         resident engine: compute units to use (0 = all; one of them walks the chain, the others stream)
+ *   pivots          resident engine: 1 = take the Gram terms of markers whose effect is non-zero at sweep start when a column is
+ *                   streamed (their events need no round trip); default 0 (measured slower on MI355X)
+ *   res_timeout_ms  resident engine: longest wait of any workgroup for another before the sweep is abandoned with an error
+ *                   (default 2000); res_deadline_ms: the host's own deadline for the kernel (0 = derived from M)
  *   batch           speculative batch width, 1..256 (0 auto)
  *   cols_per_group  batch columns per workgroup: 2, 4 (default), 8, 16
  *   slices          most tile-group slices per column group, 1..64 (0 auto)
@@ -179,6 +190,8 @@ typedef struct {
      * advanced the window, posterior chunks evaluated, chunks that had to wait for dots streamed behind the last message */
     uint64_t rounds, events, advances, chunks, refolds;
     uint64_t pivots;          /* resident engine: events that needed no round trip (predicted pivots whose Gram terms came with the columns) */
+    uint64_t predicted;       /* resident engine, the census of why rounds end: events at markers whose effect was non-zero at sweep start
+                               * (certain to change); events - predicted came unannounced; advances = rounds that ran out of window */
     double shader_mhz;        /* resident engine: s_memtime ticks per microsecond over the sweep (the clock the walker's compute unit held) */
     uint64_t ticks[16];       /* resident engine with option debug_timing: 100 MHz ticks, walker [0] fold [1] collect [2] evaluate
                                * [3] scan + draw [4] message + results + prefetch; streaming workgroup 0: [8] wait [9] update [10] Gram [11] stream */
