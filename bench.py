@@ -462,47 +462,79 @@ def main():
     lo, hi = min(N, rank * per), min(N, (rank + 1) * per)
 
     exchange = "none"
+    want_p2p, resident_ok = False, True
     if world > 1:
         want_p2p = args.exchange in ("auto", "p2p") and os.environ.get("HGIBBS_DISABLE_P2P", "0") != "1"
-        resident_ok = True
         if want_p2p and args.exchange == "auto":
             want_p2p, resident_ok = exchange_self_check(capi, dist, world, rank, local_rank)
-        dev, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
-        exchange = "p2p-mailbox" if p2p else ("rccl-allreduce" if BULK == "rccl" else "gloo-allreduce (host)")
-        if not resident_ok:
-            dev.set_option("engine", 1)  # the resident engine's cross-rank sums did not reproduce the batch engine's here: not used
-    else:
-        dev = capi.Device(local_rank)
-    if args.batch:
-        dev.set_option("batch", args.batch)
-    if args.cpg:
-        dev.set_option("cols_per_group", args.cpg)
-    if args.max_seg:
-        dev.set_option("max_seg", args.max_seg)
-    if args.graph >= 0:
-        dev.set_option("graph", args.graph)
-    for kv in args.opt:
-        name, _, val = kv.partition("=")
-        dev.set_option(name, int(val))
-
-    t_setup = time.perf_counter()
-    dev.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)
-    y_loc = make_phenotype_on_device(dev, N, M, (lo, hi), seed=43, causal_frac=args.causal_frac)
-    if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, y_loc)
-        y = np.concatenate(parts)
-    else:
-        y = y_loc
-    chain = capi.Chain(dev, y, mS=np.array(mS), groups=groups, seed=1222, shuffle=1)
-    t_setup = time.perf_counter() - t_setup
 
     def sync():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        chain.iterate()
+    def build_problem(force_batch_engine):
+        """Handle, data and chain of the timed run (every collective in here is executed by every rank)."""
+        nonlocal exchange
+        if world > 1:
+            d, p2p = make_multirank_device(capi, dist, world, rank, local_rank, want_p2p)
+            exchange = "p2p-mailbox" if p2p else ("rccl-allreduce" if BULK == "rccl" else "gloo-allreduce (host)")
+        else:
+            d = capi.Device(local_rank)
+        if force_batch_engine:
+            d.set_option("engine", 1)
+        if args.batch:
+            d.set_option("batch", args.batch)
+        if args.cpg:
+            d.set_option("cols_per_group", args.cpg)
+        if args.max_seg:
+            d.set_option("max_seg", args.max_seg)
+        if args.graph >= 0:
+            d.set_option("graph", args.graph)
+        for kv in args.opt:
+            name, _, val = kv.partition("=")
+            d.set_option(name, int(val))
+        d.synth_bed(N, M, seed=42, missing_rate=args.missing, row_begin=lo, row_end=hi)
+        y_loc = make_phenotype_on_device(d, N, M, (lo, hi), seed=43, causal_frac=args.causal_frac)
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, y_loc)
+            yy = np.concatenate(parts)
+        else:
+            yy = y_loc
+        return d, yy, capi.Chain(d, yy, mS=np.array(mS), groups=groups, seed=1222, shuffle=1)
+
+    t_setup = time.perf_counter()
+    dev, y, chain = build_problem(not resident_ok)  # (not resident_ok: the resident engine's cross-rank sums did not reproduce the batch engine's in the self-check)
+    t_setup = time.perf_counter() - t_setup
+
+    # warm-up.  Several ranks: if the sweep fails on ANY rank at the full size (the resident engine's exchange has been rehearsed on one
+    # GPU only; its waits are bounded, a rank that loses its peers comes back with an error), every rank rebuilds the problem on the
+    # batch engine and the run goes on there -- said on stderr and in config.exchange.
+    for w in range(args.warmup):
+        ok = 1
+        try:
+            chain.iterate()
+        except Exception as e:
+            if world == 1:
+                raise
+            print("rank %d: warm-up iteration %d failed: %r" % (rank, w, e), file=sys.stderr)
+            ok = 0
+        if world > 1:
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag[0]):
+                if rank == 0:
+                    print("a rank failed in the warm-up: the timed run uses the batch engine", file=sys.stderr)
+                try:
+                    dev.close()
+                except Exception:
+                    pass
+                dev, y, chain = build_problem(True)
+                exchange += " (batch engine after a failed warm-up)"
+                for _ in range(args.warmup):
+                    chain.iterate()
+                break
 
     sync()
     stats, step_s = [], []

@@ -25,8 +25,6 @@ VARIANTS = [("plain: gram=0, batch 200", {"gram": 0, "batch": 200}),
             ("carry on, ahead 64", {"carry": 1, "ahead": 64}),
             ("four segments, carry on, ahead 128", {"max_seg": 4, "carry": 1, "ahead": 128}),
             ("8 slices, cols_per_group 8", {"slices": 8, "cols_per_group": 8})]
-if MISSING > 0.0:  # the resident engine takes shards without missing calls (it refuses others)
-    VARIANTS = [v for v in VARIANTS if v[1].get("engine") != 2]
 devs = []
 for name, opts in VARIANTS:
     dev = capi.Device(0)
