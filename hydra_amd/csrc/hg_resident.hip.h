@@ -769,7 +769,7 @@ struct WalkShared {
     uint32_t* fl;   // 64 words of flags
     int32_t* lcass; // [256]
 };
-enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7, WF_CAND = 8, WF_NADA = 9, WF_COVER = 10 };
+enum { WF_FOUND = 0, WF_Q = 1, WF_K = 2, WF_RPOS = 3, WF_ERR = 4, WF_ABORT = 5, WF_FMIN = 6, WF_RDONE = 7, WF_CAND = 8, WF_NADA = 9, WF_COVER = 10, WF_POSTED = 11 };
 enum { WD_DBETA = 0, WD_BNEW = 1, WD_PROB = 2 };
 
 __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
@@ -1359,6 +1359,22 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                             sh.fd[WD_BNEW] = bnew;
                             sh.fd[WD_DBETA] = bold - bnew;
                             if (gerr) sh.fl[WF_ERR] = gerr;
+                            // the message leaves HERE, from the lane that drew the effect -- two barriers before the rest of the
+                            // workgroup has caught up with the decision (section 4 below skips its store).  Not when the event's
+                            // Gram terms may already be with the walker (pivots), nor when the flow control has to be consulted.
+                            const double db_now = bold - bnew;
+                            if (!p.pivots && !gerr && db_now != 0.0 && seq + 4u <= sh.fl[WF_RDONE] + (uint32_t)RS_MSG - 3u) {
+                                const uint32_t nc = qc - C + 1u;
+                                const uint32_t kf = (uint32_t)RS_EVENT | (C + nc >= M ? (uint32_t)RS_LAST : 0u);
+                                const unsigned long long db = (unsigned long long)__double_as_longlong(db_now);
+                                if (DBG) {
+                                    p.trace[2 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+                                    p.trace[3 * RS_TRACE + seq % RS_TRACE] = nc;
+                                    p.trace[0 * RS_TRACE + (seq + 1u) % RS_TRACE] = wall_clock64();
+                                }
+                                rs_store16(p.msg + ((seq + 1u) % RS_MSG), rs_u4((kf << 28) | nc, seq + 1u, (uint32_t)db, (uint32_t)(db >> 32)));
+                                sh.fl[WF_POSTED] = 1u;
+                            }
                         } else {
                             sh.fl[WF_CAND] = 0xffffffffu; // too close to call, and no event: on to the next candidate
                         }
@@ -1436,12 +1452,13 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         }
         __syncthreads();
         ++seq;
-        if (DBG && tid == 0) {
+        const bool posted = tid == 0 && sh.fl[WF_POSTED] != 0u; // (thread 0 wrote it, reads it and clears it: nobody else looks)
+        if (DBG && tid == 0 && !posted) {
             p.trace[2 * RS_TRACE + (seq - 1u) % RS_TRACE] = wall_clock64();
             p.trace[3 * RS_TRACE + (seq - 1u) % RS_TRACE] = ncons;
             p.trace[0 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
-        if (tid == 0) {
+        if (tid == 0 && !posted) {
             const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE)) | (lastmsg ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
             rs_store16(p.msg + (seq % RS_MSG), rs_u4((kf << 28) | ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)));
@@ -1513,6 +1530,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         }
         if (tid == 0) {
             sh.fl[WF_FOUND] = 0u;
+            sh.fl[WF_POSTED] = 0u;
         }
         __syncthreads();
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
