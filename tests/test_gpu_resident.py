@@ -188,3 +188,29 @@ def test_refused_where_it_does_not_apply(oracle):
     ch = capi.Chain(dev, y, seed=1)
     with pytest.raises(capi.HgError, match="resident engine does not apply"):
         ch.iterate()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_configurations_match_the_oracle(oracle, case):
+    """Seeded random combinations of shape (ragged N, M), mixture size, groups, share of columns with missing calls and their rate,
+    causal share, window, compute units in use (one or two tiles per workgroup) and predicted pivots: four iterations against the
+    oracle each, on the resident engine."""
+    rng = np.random.default_rng(7000 + case)
+    N = int(rng.choice([61, 700, 4097, 9000, 20011]))
+    M = int(rng.integers(40, 900))
+    K = int(rng.integers(2, 9))
+    G = int(rng.choice([1, 1, 2, 3]))
+    mS = np.sort(rng.uniform(1e-5, 0.5, size=(G, K - 1)), axis=1)
+    mS = np.concatenate([np.zeros((G, 1)), mS], axis=1)
+    groups = None if G == 1 else rng.integers(0, G, size=M).astype(np.int32)
+    if groups is not None:
+        groups[:G] = np.arange(G)  # every group has a marker
+    missing_cols = float(rng.choice([0.0, 0.0, 0.2, 1.0]))
+    opts = {"window": int(rng.choice([8, 32, 128, 256]))}
+    tiles = (N + 4095) // 4096 * 4  # wave tiles of the padded shard
+    if tiles > 1 and rng.random() < 0.5:
+        opts["res_cus"] = (tiles + 1) // 2 + 1  # two tiles per workgroup
+    if missing_cols == 0.0 and rng.random() < 0.3:
+        opts["pivots"] = 1
+    run_vs_oracle(oracle, M, N, iters=4, groups=groups, mS=mS, opts=opts, seed=int(rng.integers(1, 1 << 30)), causal_frac=float(rng.choice([0.01, 0.05, 0.3])),
+                  missing_rate=0.03 if missing_cols > 0.0 else 0.0, missing_cols=missing_cols)
