@@ -257,6 +257,22 @@ __device__ __forceinline__ int32_t rs_lane_ids()
     return v;
 }
 
+// four 64-lane integer sums at once (hg_sweep.hip.h: wave_sum_u32), step by step over the four: totals returned wave-uniform
+__device__ __forceinline__ void wave_sum_u32x4(uint32_t (&v)[4])
+{
+#define RS_STEP(ctrl, rmask)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[k], ctrl, rmask, 0xF, false);
+    RS_STEP(0xB1, 0xF)  // quad_perm [1,0,3,2]
+    RS_STEP(0x4E, 0xF)  // quad_perm [2,3,0,1]
+    RS_STEP(0x141, 0xF) // row_half_mirror
+    RS_STEP(0x140, 0xF) // row_mirror
+    RS_STEP(0x142, 0xA) // row_bcast15
+    RS_STEP(0x143, 0xC) // row_bcast31
+#undef RS_STEP
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (uint32_t)__builtin_amdgcn_readlane((int)v[k], 63);
+}
+
 // 64-lane sum of a double on the DPP path, fixed order; the total is in lane 63 (rows that a step does not write add +0.0)
 __device__ __forceinline__ double rs_wave_sum_f64(double v)
 {
@@ -508,12 +524,16 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     }
                 }
             }
+            // wave sums of the packed accumulators, four at a time: a sum is a chain of six dependent DPP steps (~20 clocks each), four
+            // independent chains share the waiting
             uint32_t mine = 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if ((uint32_t)(2 * r) < Vw) { // wave-uniform
-                    const uint32_t tot = wave_sum_u32(acc[r]);
-                    mine = (lane == 2 * r) ? (tot & 0xffffu) : ((lane == 2 * r + 1) ? (tot >> 16) : mine);
+            for (int r0 = 0; r0 < 16; r0 += 4) {
+                if ((uint32_t)(2 * r0) < Vw) { // wave-uniform
+                    uint32_t tot[4] = {acc[r0], acc[r0 + 1], acc[r0 + 2], acc[r0 + 3]};
+                    wave_sum_u32x4(tot);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mine = (lane == 2 * (r0 + k)) ? (tot[k] & 0xffffu) : ((lane == 2 * (r0 + k) + 1) ? (tot[k] >> 16) : mine);
                 }
             }
             if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words: count in the top byte
