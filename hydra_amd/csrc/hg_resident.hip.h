@@ -1339,23 +1339,28 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                         const double ex = exp(d);
                         const bool bigp = on && l >= (kk ? kk : 1) && fabs(d) > 700.0;
                         const unsigned long long bm = __ballot(bigp);
-                        double sum = 0.0;
+                        // the group's sum in component order, in the group's first lane: its neighbours' terms come by DPP shifts (a
+                        // crossbar shuffle per term was ~100 clocks each, on the chain)
+                        double sum = ex, cur = ex;
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) {
-                            const double v = __shfl(ex, (lane & ~7) + x, 64);
-                            if (x < K) sum += v;
+                        for (int x = 1; x < 8; ++x) {
+                            cur = rs_dpp_f64<0x101>(cur); // row_shl:1 -- lane i takes lane i + 1's
+                            if (x < K) sum += cur;        // wave-uniform
                         }
                         const bool anyb = ((bm >> (lane & ~7)) & 0xffull) != 0ull;
-                        const double thr = anyb ? 0.0 : 1.0 / sum; // of walk step kk, the same value in the 8 lanes of its group
+                        const double thr = anyb ? 0.0 : 1.0 / sum; // of walk step kk, valid in the first lane of its group
                         k = K - 1;
                         double acum = 0.0;
                         bool fnd = false;
-                        for (int sidx = 0; sidx + 1 < K; ++sidx) {
-                            const double t = __shfl(thr, 8 * sidx, 64);
-                            acum = sidx ? acum + t : t;
-                            if (!fnd && prob <= acum) {
-                                k = sidx;
-                                fnd = true;
+#pragma unroll
+                        for (int sidx = 0; sidx < 7; ++sidx) {
+                            if (sidx + 1 < K) { // wave-uniform
+                                const double t = rs_readlane(thr, 8 * sidx);
+                                acum = sidx ? acum + t : t;
+                                if (!fnd && prob <= acum) {
+                                    k = sidx;
+                                    fnd = true;
+                                }
                             }
                         }
                         if (lane == 0 && k > 0) {
@@ -1365,9 +1370,9 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                             consumed = g.pos - pos;
                             gerr = g.err;
                         }
-                        bnew = __shfl(bnew, 0, 64);
-                        consumed = (uint32_t)__shfl((int)consumed, 0, 64);
-                        gerr = (uint32_t)__shfl((int)gerr, 0, 64);
+                        bnew = rs_readlane(bnew, 0);
+                        consumed = (uint32_t)__builtin_amdgcn_readlane((int)consumed, 0);
+                        gerr = (uint32_t)__builtin_amdgcn_readlane((int)gerr, 0);
                     }
                     const bool is_ev = k != 0 || bold != 0.0;
                     if (lane == 0) {
