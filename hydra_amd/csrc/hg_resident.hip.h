@@ -162,6 +162,15 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
 }
 
 __host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 97 + (size_t)B * 256 * T; }
+// build MISS: a copy of the workgroup's eps slice in LDS, addressable by individual ([(16 t + slot) * 64 + lane] doubles), for the sums
+// over a column's (few) missing calls.  The build keeps two group sums per refilled position instead of eight and no pivot terms: the
+// copy lives in what that frees of the plain layout (between 512 + 32 B and the ring) when it fits there, else behind the ring.
+__host__ __device__ inline size_t rs_epsl_off(uint32_t B, int T) { return ((size_t)B * 65 >= (size_t)8192 * T) ? 512 + (size_t)B * 32 : rs_streamer_lds(B, T); }
+__host__ __device__ inline size_t rs_streamer_lds_miss(uint32_t B, int T)
+{
+    const size_t a = rs_streamer_lds(B, T), b = rs_epsl_off(B, T) + (size_t)8192 * T;
+    return a > b ? a : b;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
@@ -345,6 +354,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     uint32_t* const pterm = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 81);  // this round's refill: [position - Sx][RS_PMAX] Gram terms with the batch's pivots
     uint32_t* const pivl = reinterpret_cast<uint32_t*>(smem + 320);                    // [0] = number of the batch's pivots, [1 ..] their positions
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 97);  // [B][64 * T] codes of the window columns
+    double* const epsl = reinterpret_cast<double*>(smem + rs_epsl_off(B, T));           // build MISS: the eps slice by individual (see rs_epsl_off)
     const bool timing = DBG && wg == 0 && tid == 0;
     unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(smem + 384); // [8] stage clocks of the debug build (in LDS: sixteen registers less)
     unsigned long long tmark = timing ? wall_clock64() : 0ull;
@@ -374,6 +384,18 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         for (int s = 0; s < IPT; ++s) e[t][s] = vgrp ? p.eps[eps_pos(i0 + (uint32_t)s)] : 0.0;
     }
 
+    // build MISS: every wave holds the same eps; wave w keeps slots w and w + 8 of the LDS copy current
+    auto eps_to_lds = [&]() {
+        if constexpr (MISS) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int sl = 0; sl < IPT; ++sl)
+                    if ((sl & 7) == wave) epsl[(uint32_t)(t * IPT + sl) * 64u + (uint32_t)lane] = e[t][sl]; // wave-uniform
+        }
+    };
+    eps_to_lds();
+    if constexpr (MISS) __syncthreads();
     uint32_t C = 0, Sx = 0, seq = 0, nev = 0;
     uint32_t kind = RS_ADVANCE, ncons = 0;
     bool last = M == 0;
@@ -459,15 +481,19 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     xqc[t] = gram_xform(cq);
                 }
                 const double mqv = mq.x;
-                double mine = 0.0;
-                for (uint32_t c0 = 0; c0 < Vw; c0 += 4u) { // wave-uniform; four columns at a time: their wave sums are four independent chains
-                    double cv[4];
+                // the four integer sums of a column meet packed (A | P << 16, Q | X << 16: a lane adds at most 128 / 64 / 64 / 32, the wave
+                // 8192 / 4096 / 4096 / 2048), four columns' wave sums at a time; lane c then holds column c's totals and forms its term
+                uint32_t ap_mine = 0u, qx_mine = 0u;
+                double mj_mine = 0.0;
+                for (uint32_t c0 = 0; c0 < Vw; c0 += 4u) { // wave-uniform
+                    uint32_t ap[4], qx[4];
+                    double mjs[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t i = i0 + c0 + (uint32_t)k;
                         const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
                         const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-                        const double mj = meta[slot].x;
+                        mjs[k] = meta[slot].x;
                         uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
@@ -479,16 +505,20 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                             Q += (uint32_t)__popc(xqc[t] & mj2);
                             X += (uint32_t)__popc(mj1 & mq1[t]);
                         }
-                        cv[k] = ((double)A + mqv * (double)P) + (mj * (double)Q + (mj * mqv) * (double)X);
+                        ap[k] = A | (P << 16);
+                        qx[k] = Q | (X << 16);
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) cv[k] = rs_wave_sum_f64(cv[k]);
+                    wave_sum_u32x4(ap);
+                    wave_sum_u32x4(qx);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const double tot = rs_readlane(cv[k], 63);
-                        mine = (uint32_t)lane == c0 + (uint32_t)k ? tot : mine;
+                        const bool me = (uint32_t)lane == c0 + (uint32_t)k;
+                        ap_mine = me ? ap[k] : ap_mine;
+                        qx_mine = me ? qx[k] : qx_mine;
+                        mj_mine = me ? mjs[k] : mj_mine;
                     }
                 }
+                const double mine = ((double)(ap_mine & 0xffffu) + mqv * (double)(ap_mine >> 16)) + (mj_mine * (double)(qx_mine & 0xffffu) + (mj_mine * mqv) * (double)(qx_mine >> 16));
                 if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
                     const double MAGIC = 6755399441055744.0;
                     const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
@@ -540,11 +570,15 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
             }
             if (with_gram) ++nev;
+            eps_to_lds(); // (build MISS: behind the Gram terms, which are what the walker waits for; read by the refill below, behind a barrier)
             lap(2);
             if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
+        if constexpr (MISS) {
+            if (upd) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave's share of the updated LDS copy is in place
+        }
         const uint32_t round_k0 = nk; // this wave's columns of the round: k in [round_k0, nk) behind the passes
         uint32_t done_k0 = nk, done_m = 0; // the sets the last pass consumed: reloaded behind the raw dots
         while (count_w) {
@@ -573,20 +607,26 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         // weight 0 -- and R = sum of eps over the missing ones (s2 = sum of eps - R), the same three instructions per
                         // individual on the 1-bit field; both summed over the whole wave here (the LDS that would hold eight partial sums
                         // of each is the window's)
-                        double rr[4] = {0.0, 0.0, 0.0, 0.0};
+                        double rsum = 0.0;
                         if (__builtin_amdgcn_readlane(gal, r) & 0x20000000) { // wave-uniform
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                const uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
+                                uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
                                 fma_col(gw[t] & ~(mm | (mm << 1)), e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
-                                fma_col(mm, e[t], rr[0], rr[1], rr[2], rr[3], std::make_integer_sequence<int, IPT / 4>{});
+                                // the few missing calls of the lane's dword, one by one (the reference's index-list form,
+                                // src/BayesRRm.cpp:331-341: a gather over ~1 % of the individuals): eps by individual comes from the LDS copy
+                                while (mm) { // per lane; the wave goes round as often as its fullest lane needs
+                                    const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+                                    rsum += epsl[((uint32_t)(t * IPT) + (b >> 1)) * 64u + (uint32_t)lane];
+                                    mm &= mm - 1u;
+                                }
                             }
                         } else {
 #pragma unroll
                             for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
                         }
                         const double v = rs_wave_sum_f64((a[0] + a[1]) + (a[2] + a[3]));
-                        const double w = rs_wave_sum_f64((rr[0] + rr[1]) + (rr[2] + rr[3]));
+                        const double w = rs_wave_sum_f64(rsum);
                         if (lane == 63) {
                             part[(pos - Sx) * 2u] = v;
                             part[(pos - Sx) * 2u + 1u] = w;
@@ -613,7 +653,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));
                 if (lane < RS_PF && kl - nk < m) {
                     meta[pos_of(kl) & bmask] = rs_lane_meta();
-                    pflag[pos_of(kl) & bmask] = (uint8_t)(rs_lane_bold() != 0.0 ? 1 : 0);
+                    if constexpr (!MISS) pflag[pos_of(kl) & bmask] = (uint8_t)(rs_lane_bold() != 0.0 ? 1 : 0); // (build MISS: no pivots; the LDS copy of eps lives there)
                     lane_load(pos_of(kl + (uint32_t)RS_PF), pos_of(kl + 2u * (uint32_t)RS_PF));
                 }
             }

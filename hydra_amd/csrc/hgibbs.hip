@@ -1333,7 +1333,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
-    const size_t lds = std::max(rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
+    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
     void (*kern)(ResParams, const ResParams*) = nullptr;
     const bool dbg = h->debug_timing;
     const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
