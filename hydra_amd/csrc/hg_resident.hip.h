@@ -448,8 +448,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (tid < 16) {
                 const double av = mq.x, sd = mq.y, db = dbeta;
                 const double v0 = -(av * sd * db), v1 = db * (1.0 - av) * sd, v2 = db * (2.0 - av) * sd;
-                // (window codes: the x form 00 / 01 / 11 = genotype 0 / 1 / 2; build MISS: the device codes, 11 = missing call, addend 0)
-                auto addend = [&](uint32_t c) { return 0.0 + ((c == 0u) ? v0 : ((c == 1u) ? v1 : ((c == (MISS ? 2u : 3u)) ? v2 : 0.0))); };
+                // (window codes: the x form 00 / 01 / 11 = genotype 0 / 1 / 2; 10 = missing call, addend 0)
+                auto addend = [&](uint32_t c) { return 0.0 + ((c == 0u) ? v0 : ((c == 1u) ? v1 : ((c == 3u) ? v2 : 0.0))); };
                 tab[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
             }
             __syncthreads();
@@ -473,12 +473,11 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 GramPivot gp[T];
                 uint32_t xqc[T], mq1[T], mq2[T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    mq1[t] = xq[t] & (xq[t] >> 1) & 0x55555555u;
+                for (int t = 0; t < T; ++t) { // window code 10 = missing: its mask, and the x form with those fields cleared
+                    mq1[t] = (xq[t] >> 1) & ~xq[t] & 0x55555555u;
                     mq2[t] = mq1[t] | (mq1[t] << 1);
-                    const uint32_t cq = xq[t] & ~mq2[t];
-                    gp[t] = gram_pivot(cq);
-                    xqc[t] = gram_xform(cq);
+                    xqc[t] = xq[t] & ~mq2[t];
+                    gp[t] = gram_pivot_x(xqc[t]);
                 }
                 const double mqv = mq.x;
                 // the four integer sums of a column meet packed (A | P << 16, Q | X << 16: a lane adds at most 128 / 64 / 64 / 32, the wave
@@ -498,8 +497,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
                             const uint32_t w = rp[t];
-                            const uint32_t mj1 = w & (w >> 1) & 0x55555555u, mj2 = mj1 | (mj1 << 1);
-                            const uint32_t xj = gram_xform(w & ~mj2);
+                            const uint32_t mj1 = (w >> 1) & ~w & 0x55555555u, mj2 = mj1 | (mj1 << 1);
+                            const uint32_t xj = w & ~mj2;
                             A += gram16x(xj, gp[t]);
                             P += (uint32_t)__popc(xj & mq2[t]);
                             Q += (uint32_t)__popc(xqc[t] & mj2);
@@ -599,9 +598,12 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr));
                     const uint32_t slot = pos & bmask;
                     uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+                    // the window keeps the x form (00, 01, 11 for genotype 0, 1, 2; a missing call is the free code 10): what the update's table
+                    // and the Gram terms of EVERY later event need, made once
+                    if constexpr (!MISS) {
 #pragma unroll
-                    for (int t = 0; t < T; ++t) rp[t] = MISS ? gw[t] : gram_xform(gw[t]); // the window keeps the x form (00, 01, 11 for genotype 0, 1, 2): what the Gram terms of
-                                                                                          // EVERY later event need, made once; with missing calls the codes as they are (11 = missing)
+                        for (int t = 0; t < T; ++t) rp[t] = gram_xform(gw[t]);
+                    }
                     if constexpr (MISS) {
                         // a column with missing calls (:1785-1790): s1 over the calls that are there -- the missing ones' fields are cleared,
                         // weight 0 -- and R = sum of eps over the missing ones (s2 = sum of eps - R), the same three instructions per
@@ -609,21 +611,28 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         // of each is the window's)
                         double rsum = 0.0;
                         if (__builtin_amdgcn_readlane(gal, r) & 0x20000000) { // wave-uniform
+                            unsigned long long mall = 0ull; // the lane's missing calls of all its dwords: bit 32 t + 2 s
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
-                                fma_col(gw[t] & ~(mm | (mm << 1)), e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
-                                // the few missing calls of the lane's dword, one by one (the reference's index-list form,
-                                // src/BayesRRm.cpp:331-341: a gather over ~1 % of the individuals): eps by individual comes from the LDS copy
-                                while (mm) { // per lane; the wave goes round as often as its fullest lane needs
-                                    const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
-                                    rsum += epsl[((uint32_t)(t * IPT) + (b >> 1)) * 64u + (uint32_t)lane];
-                                    mm &= mm - 1u;
-                                }
+                                const uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
+                                const uint32_t clean = gw[t] & ~(mm | (mm << 1));
+                                fma_col(clean, e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                                rp[t] = gram_xform(clean) | (mm << 1);
+                                mall |= (unsigned long long)mm << (32 * t);
+                            }
+                            // the few missing calls of the lane, one by one (the reference's index-list form, src/BayesRRm.cpp:331-341:
+                            // a gather over ~1 % of the individuals): eps by individual comes from the LDS copy ([(16 t + s) * 64 + lane])
+                            while (mall) { // per lane; the wave goes round as often as its fullest lane needs
+                                const uint32_t b = (uint32_t)__ffsll((long long)mall) - 1u;
+                                rsum += epsl[(b >> 1) * 64u + (uint32_t)lane];
+                                mall &= mall - 1ull;
                             }
                         } else {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                            for (int t = 0; t < T; ++t) {
+                                fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                                rp[t] = gram_xform(gw[t]);
+                            }
                         }
                         const double v = rs_wave_sum_f64((a[0] + a[1]) + (a[2] + a[3]));
                         const double w = rs_wave_sum_f64(rsum);
