@@ -1262,6 +1262,8 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
 static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
 {
     const int G = h->G, K = h->K;
+    static const bool timing = std::getenv("HGIBBS_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     double r0[2];
     if (reduce_eps_all(h, r0)) return 1; // (sum, sum of squares) over all individuals
     ResParams p{};
@@ -1387,6 +1389,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
             if (el > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.5 ? 2000 : 50));
         }
     }
+    const auto t_kernel = std::chrono::steady_clock::now();
     const ResState& st = *h->res_state_host;
     if (st.error)
         return fail("hgibbs_sweep: resident engine abort code %u at cursor %u (2 = rng staging overrun, 3 = a workgroup timed out, 5 = raw dot outside the fixed-point range)", st.error, st.cursor);
@@ -1422,6 +1425,11 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         if (reduce_eps_all(h, r1)) return 1;
         s.eps_sum_drift = std::fabs(r1[0] - r0[0]);
     }
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[hgibbs] resident sweep: host until the kernel is back %.3f ms (device %.3f), results + drift %.3f\n", ms(t_0, t_kernel), (double)s.device_ms,
+                     ms(t_kernel, std::chrono::steady_clock::now()));
+    }
     return 0;
 }
 
@@ -1433,6 +1441,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     if (!h || !h->bed) return fail("hgibbs_sweep: no data loaded");
     if (h->G < 1) return fail("hgibbs_sweep: model not set");
     if (!order_host || !sigmaG_host || !estPi_host || !adaV_host || !rng) return fail("hgibbs_sweep: null argument");
+    const auto t_prep0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(h->device));
     if (compute_stats(h)) return 1;
     const int G = h->G, K = h->K;
@@ -1512,6 +1521,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         if (std::getenv("HGIBBS_DEBUG"))
             std::fprintf(stderr, "[hgibbs] engine: %s%s%s\n", plan.ok ? "resident" : "batch", why ? " -- resident refused: " : "", why ? why : "");
     }
+    if (std::getenv("HGIBBS_TIMING"))
+        std::fprintf(stderr, "[hgibbs] sweep preparation (checks, tables, order / adaV upload, metadata gather) %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
     if (plan.ok) return sweep_resident(h, plan, sigmaE, rng, cass_host, nnz_updates);
 
     SweepParams p{};

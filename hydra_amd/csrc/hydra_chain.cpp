@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/hgibbs.h"
@@ -180,6 +183,11 @@ int hydra_chain_iterate(hydra_chain_t c)
     const int G = c->G, K = c->K;
     const double dN = (double)c->N;
     hg::Mt gen{c->rng.x, c->rng.idx};
+    // HGIBBS_TIMING=1: where the host side of an iteration goes (stderr, milliseconds)
+    static const bool timing = std::getenv("HGIBBS_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_0 = tnow();
 
     // :1675-1686
     if (hgibbs_add_scalar(c->dev, c->mu)) return 1;
@@ -188,11 +196,13 @@ int hydra_chain_iterate(hydra_chain_t c)
     c->mu = hg::norm_rng(gen, epssum / dN, c->sigmaE / dN);
     if (hgibbs_add_scalar(c->dev, -c->mu)) return 1;
 
+    const auto t_mu = tnow();
     // :1691-1694
     if (c->shuffle) {
         hg::shuffle_libstdcxx6(c->order.data(), c->order.size(), gen);
     }
     std::fill(c->m0.begin(), c->m0.end(), 0);
+    const auto t_shuffle = tnow();
 
     // :1709-2490 on the device; the generator travels with the call
     c->rng.idx = gen.idx;
@@ -200,10 +210,12 @@ int hydra_chain_iterate(hydra_chain_t c)
                      c->cass.data(), &c->last_nnz))
         return 1;
     gen.idx = c->rng.idx;
+    const auto t_sweep = tnow();
 
     // :2495-2578
     std::vector<double> bsq(G, 0.0);
     if (hgibbs_beta_sqnorm(c->dev, bsq.data())) return 1;
+    const auto t_bsq = tnow();
     std::vector<double> dirin(K), pi(K);
     for (int g = 0; g < G; ++g) {
         if (c->MtotGrp[g] == 0) continue;
@@ -246,6 +258,9 @@ int hydra_chain_iterate(hydra_chain_t c)
     c->sigmaE = hg::inv_scaled_chisq_rng(gen, V0E + dN, (e_sqn + V0E * S02E) / (V0E + dN));
     c->rng.idx = gen.idx;
     c->iteration += 1;
+    if (timing)
+        std::fprintf(stderr, "[hydra_chain] iteration %u: mu %.3f  shuffle %.3f  sweep call %.3f  beta sqnorm %.3f  hyper-parameters + sigmaE %.3f  | %.3f ms\n", c->iteration - 1,
+                     tms(t_0, t_mu), tms(t_mu, t_shuffle), tms(t_shuffle, t_sweep), tms(t_sweep, t_bsq), tms(t_bsq, tnow()), tms(t_0, tnow()));
     return 0;
 }
 

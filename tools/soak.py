@@ -22,6 +22,7 @@ VARIANTS = [("plain: gram=0, batch 200", {"gram": 0, "batch": 200}),
             ("batch engine, defaults", {"engine": 1}),
             ("resident engine", {"engine": 2}),
             ("resident engine, window 64, predicted pivots", {"engine": 2, "window": 64, "pivots": 1}),
+            ("resident engine, window 128, 250 compute units", {"engine": 2, "window": 128, "res_cus": 250}),
             ("carry on, ahead 64", {"carry": 1, "ahead": 64}),
             ("four segments, carry on, ahead 128", {"max_seg": 4, "carry": 1, "ahead": 128}),
             ("8 slices, cols_per_group 8", {"slices": 8, "cols_per_group": 8})]
