@@ -111,16 +111,16 @@ def test_two_ranks_one_gpu_p2p_exchange(batch, M, N, world, miss):
     assert res[0][6] == ch.last_nnz()
 
 
-@pytest.mark.parametrize("M,N,world,opts", [(400, 9000, 2, {}), (500, 21000, 3, {"window": 64}), (300, 30000, 2, {"res_cus": 9})])
-def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts):
+@pytest.mark.parametrize("M,N,world,opts,iters", [(400, 9000, 2, {}, 3), (500, 21000, 3, {"window": 64}, 3), (300, 30000, 2, {"res_cus": 9}, 3),
+                                                  (2500, 70000, 2, {}, 8)])
+def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts, iters):
     """The resident engine sharded over ranks (here: processes that share device 0; the mailboxes are IPC-mapped memory as between
     GPUs): every rank runs one resident kernel on its shard, the walkers are replicas that add the peers' integer Gram sums and
     fixed-point raw dots from their mailboxes.  Replicas bit-identical; equal to the CPU oracle's chain on the whole data
-    (components, cass exact; beta, Acum, residual to 1e-9).  Ragged shards (three ranks), a small window, two tiles per workgroup."""
+    (components, cass exact; beta, Acum, residual to 1e-9).  Ragged shards (three ranks), a small window, two tiles per workgroup; a longer chain on 35 workgroups per rank (20 000 messages exchanged)."""
     import torch.multiprocessing as mp
     import orc
     from hydra_amd import synth
-    iters = 3
     geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.0)
     y, _ = synth.make_phenotype(geno, seed=72, causal_frac=0.05)
     bed = synth.pack_bed_columns(geno)
