@@ -45,6 +45,7 @@ constexpr uint32_t RS_ONE = 1u << 24;     // a Gram accumulator word carries its
 constexpr uint32_t RS_LOW = RS_ONE - 1u;
 constexpr unsigned long long RS_ONE64 = 1ull << 56; // build MISS: the same in an 8-byte word (the sum below is fixed point, units of 2^-RS_GFX)
 constexpr int RS_GFX = 32;                // a workgroup's four-term sum is < 2^15 (four terms of at most 4 * 2048 each): 47 bits, 55 over 255 workgroups
+constexpr int RS_FG = 4, RS_FN = 256;      // the walker's tabulated bound: groups it is kept for, intervals of its grid
 constexpr int RX_MAXR = 8;                // ranks the engine shards over (one node of eight GPUs; more fall back to the batch engine): the walker keeps a load per peer in flight
 constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marker was an event (the walker wrote its component); cleared by k_res_finish
 
@@ -814,7 +815,10 @@ struct WalkShared {
     uint32_t* batch; // refill batch (= message number) that streamed the slot's column
     uint32_t* gpart; // [RS_NSH][RS_BMAX] the shards' Gram sums of the event being collected
     unsigned long long* rprev; // [RS_RB] sum over the shards of the raw-dot words as last seen (they only ever grow)
-    double* tq;     // [MT_BUF] per word of the staged generator blocks: the largest max_l (logL_l - logL_0) that cannot give an event
+    double* tq;     // [MT_BUF] per word of the staged generator blocks: the largest log sum_l>0 exp(logL_l - logL_0) (or, without the table
+                    // below, the largest max_l (logL_l - logL_0)) that cannot give an event
+    double* ftab;   // [RS_FG][RS_FN + 1] per group: f(n2) = log sum_l>0 exp(c_l + n2 r_l) at n2 = k / fscale (convex: the chord is an upper bound)
+    double* fscale; // [RS_FG] grid intervals per unit of n2
     double* qtab;   // [2][HT_LDS]: per (group, component) c = logpi - hlog - logpi_0 and r = 1 / (2 sigmaE denom)
     uint16_t* crank; // [RS_BMAX] rank of the window position among the markers that take a uniform (adaV), this walk
     uint32_t* bl_pos; // [RS_NB][RS_PMAX] the pivots of a refill batch (positions, in order), by batch number mod RS_NB
@@ -864,6 +868,8 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.rprev2 = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
     s.gpart64 = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_NSH * RS_BMAX * 8;
     s.tq = reinterpret_cast<double*>(q); q += (size_t)MT_BUF * 8;
+    s.ftab = reinterpret_cast<double*>(q); q += (size_t)RS_FG * (RS_FN + 1) * 8;
+    s.fscale = reinterpret_cast<double*>(q); q += (size_t)RS_FG * 8;
     s.qtab = reinterpret_cast<double*>(q); q += (size_t)2 * HT_LDS * 8;
     s.fd = reinterpret_cast<double*>(q); q += 64 * 8;
     s.marker = reinterpret_cast<int32_t*>(q); q += (size_t)B * 4;
@@ -924,10 +930,16 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
     // tq[i]: with prob = the uniform of generator word i, no event iff prob <= 1 / sum_l exp(d_l) (d_l = logL_l - logL_0, d_0 = 0,
     // :1883-1921), which holds whenever (K - 1) exp(max_l d_l) <= 1 / prob - 1: max_l d_l <= log((1 / prob - 1) / (K - 1)).  The
     // margin covers the roundings of the quick form of d_l below; a marker beyond it is decided by the exact arithmetic.
+    // Tighter, where the mixture tables are in LDS and the groups are few: f(n2) = log sum_l>0 exp(c_l + n2 r_l) is convex in n2 =
+    // num^2, so between two grid points its chord lies above it -- no event iff f(n2) <= log(1 / prob - 1), tested against the
+    // chord (an upper bound; the bound with the factor K - 1 sent a quarter of the exact phases after markers that were no events).
+    // The grid covers f up to 40 + c (beyond every possible threshold: prob >= 2^-32); n2 beyond it is a candidate.
+    const bool use_ftab = lds_tab && p.GK / K <= RS_FG;
     auto stage_tq = [&](int lo, int hi) {
+        const double div = use_ftab ? 1.0 : (double)(K - 1);
         for (int i = lo + tid; i < hi; i += RS_BLOCK) {
             const double prob = (double)mt_temper(sh.mt[i]) * (1.0 / 4294967296.0);
-            sh.tq[i] = log((1.0 / prob - 1.0) / (double)(K - 1)) - 1e-9;
+            sh.tq[i] = log((1.0 / prob - 1.0) / div) - 1e-9;
         }
     };
     if (lds_tab)
@@ -1003,6 +1015,28 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
     uint32_t pf_n = 0; // fired pivots on record (sh.pf_*)
     prefetch(0u, Sx, 0u);
     __syncthreads();
+    if (use_ftab) {
+        const int G = p.GK / K;
+        if (tid < G) {
+            double rmin = 1e300, cmin = 1e300;
+            for (int l = 1; l < K; ++l) {
+                rmin = fmin(rmin, sh.qtab[HT_LDS + tid * K + l]);
+                cmin = fmin(cmin, sh.qtab[tid * K + l]);
+            }
+            // (d_l = c_l + n2 r_l >= c_l: with every c_l >= -699 no exponential of the exact arithmetic underflows to its special case, :1892;
+            // scale 0: every marker of the group is a candidate)
+            sh.fscale[tid] = (rmin > 0.0 && rmin < 1e300 && cmin >= -699.0) ? (double)RS_FN * rmin / 40.0 : 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < G * (RS_FN + 1); i += RS_BLOCK) {
+            const int g = i / (RS_FN + 1), k = i % (RS_FN + 1);
+            const double sc = sh.fscale[g];
+            const double n2 = sc > 0.0 ? (double)k / sc : 0.0;
+            double sum = 0.0;
+            for (int l = 1; l < K; ++l) sum += exp(sh.qtab[g * K + l] + n2 * sh.qtab[HT_LDS + g * K + l]);
+            sh.ftab[i] = log(sum);
+        }
+    }
     stage_tq(0, MT_N);
     batch_pivots(0u, 0u, Sx);
     __syncthreads();
@@ -1335,7 +1369,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                         sh.num[slot] = num;
                         const double n2 = num * num;
                         double dmax = -1e300, dmin = 1e300;
-                        for (int l = 1; l < K; ++l) {
+                        for (int l = 1; l < K && !use_ftab; ++l) {
                             double c, r;
                             if (lds_tab) {
                                 c = sh.qtab[g0 + l];
@@ -1348,7 +1382,17 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                             dmax = d > dmax ? d : dmax;
                             dmin = d < dmin ? d : dmin;
                         }
-                        cand = cand || !(dmax <= sh.tq[rpos + myrank] && dmin >= -699.0);
+                        if (use_ftab) {
+                            const int g = sh.grp[slot];
+                            const double x = n2 * sh.fscale[g];
+                            const bool inside = x < (double)RS_FN && sh.fscale[g] > 0.0; // (NaN: outside)
+                            const int k = inside ? (int)x : 0;
+                            const double f0 = sh.ftab[g * (RS_FN + 1) + k], f1 = sh.ftab[g * (RS_FN + 1) + k + 1];
+                            const double fup = f0 + (x - (double)k) * (f1 - f0);
+                            cand = cand || !(inside && fup <= sh.tq[rpos + myrank]);
+                        } else {
+                            cand = cand || !(dmax <= sh.tq[rpos + myrank] && dmin >= -699.0);
+                        }
                     }
                     if (cand) atomicMin(&sh.fl[WF_CAND], base + (uint32_t)tid);
                     if ((uint32_t)tid == nA - 1u) sh.fl[WF_NADA] = myrank + (ada ? 1u : 0u);
