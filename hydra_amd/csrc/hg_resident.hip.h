@@ -109,6 +109,7 @@ struct ResParams {
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
+    int all_ada; // 1: no marker is frozen out (adaV all ones, the usual case): a marker's uniform is its distance from the cursor
     // several GPUs (individuals sharded over the ranks): every rank runs this kernel on its shard, the walkers are
     // replicas that decide on the SAME integer sums -- each adds its peers' parts, which arrive in its mailbox (RX_* below)
     int nranks, rank;
@@ -1349,7 +1350,11 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                 // rank among the markers that take a uniform: ballots of this wave's positions and of the waves before it
                 uint32_t before = 0;
                 unsigned long long am = 0ull;
-                for (int w = 0; w <= wv && w < 4; ++w) {
+                if (p.all_ada) { // every marker takes a uniform: the rank is the offset
+                    before = (uint32_t)wv * WAVE;
+                    am = ~0ull;
+                }
+                for (int w = 0; w <= wv && w < 4 && !p.all_ada; ++w) {
                     const uint32_t jw = (uint32_t)(w * WAVE + lane);
                     const bool a = jw < nA && sh.ada[(base + jw) & bmask] != 0;
                     const unsigned long long m = __ballot(a);

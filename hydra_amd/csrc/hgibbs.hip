@@ -146,6 +146,7 @@ struct hgibbs_ctx {
 
     // resident engine (hg_resident.hip.h): one launch per sweep, individuals sharded over the compute units
     int engine = 0;           // option engine: 0 auto (resident where it applies), 1 batch engine (k_sweep_batch), 2 resident (refused where it does not apply)
+    bool res_all_ada = false;            // this sweep's adaV has no zero
     unsigned long long res_sweep_id = 0; // resident sweeps so far: the epoch of the cross-rank mailbox flags
     bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
@@ -1327,6 +1328,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
+    p.all_ada = h->res_all_ada ? 1 : 0;
     p.sweep_id = ++h->res_sweep_id; // every rank runs the same sweeps on the resident engine (agreed in hgibbs_sweep): the counters stay equal
     p.trace = h->res_trace;
     p.progress = h->res_progress;
@@ -1524,6 +1526,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     if (std::getenv("HGIBBS_TIMING"))
         std::fprintf(stderr, "[hgibbs] sweep preparation (checks, tables, order / adaV upload, metadata gather) %.3f ms\n",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
+    h->res_all_ada = std::memchr(adaV_host, 0, (size_t)M) == nullptr;
     if (plan.ok) return sweep_resident(h, plan, sigmaE, rng, cass_host, nnz_updates);
 
     SweepParams p{};
