@@ -432,7 +432,9 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     for (;;) {
         const bool upd = kind == RS_EVENT || kind == RS_PIVOT; // RS_PIVOT: the walker has this event's Gram terms already
         const bool with_gram = kind == RS_EVENT;
-        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
+        // (progress words: a store in front of a barrier or a vmcnt(0) wait makes it wait for the store's round trip -- workgroup 0 would be the
+        // slowest of all; the timed build keeps only the stores that stand in front of a poll)
+        if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
         const uint32_t Cn = C + ncons;
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
@@ -676,7 +678,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         lap(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the window's new columns and this round's group sums are in LDS for every wave
         lap(4);
-        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
+        if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
         // ---- Gram terms with the batch's pivots.  A marker whose effect is non-zero at sweep start WILL change (a predicted event):
         // the first RS_PMAX of them in the window as it stands now, [Cn, Sn), are this batch's pivots, and every column of the batch
         // behind one of them takes its integer Gram term with it here, where both columns are in LDS -- the walker then needs no
@@ -1322,7 +1324,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         // effect is non-zero (it WILL change), or one too close to call -- is decided by wave 0 with the exact arithmetic of the
         // reference (all thresholds of its marker, :1883-1921, the component, the draw, a7); if that says "no event" after all, the
         // next candidate is looked at.  Acum of the markers that pass is computed behind the message (step 5).
-        if (tid == 0) p.progress[0] = (n_rounds << 8) | 2u;
+        if (DBG && tid == 0) p.progress[0] = (n_rounds << 8) | 2u;
         uint32_t base = C;
         bool found = false;
         while (!found && base < Sx) {
@@ -1342,7 +1344,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             }
             const uint32_t nA = F - base; // <= B <= 256 positions: threads 0 .. nA - 1
             ++n_chunks;
-            if (tid == 0) p.progress[0] = (n_rounds << 8) | 4u;
+            if (DBG && tid == 0) p.progress[0] = (n_rounds << 8) | 4u;
             bool cand = false;
             uint32_t myrank = 0;
             {
@@ -1526,7 +1528,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         }
 
         // 4. the message
-        if (tid == 0) p.progress[0] = (n_rounds << 8) | 5u;
+        if (DBG && tid == 0) p.progress[0] = (n_rounds << 8) | 5u;
         const uint32_t qpos = found ? sh.fl[WF_Q] : 0u;
         const uint32_t ncons = found ? qpos - C + 1u : Sx - C;
         const double dbeta = found ? sh.fd[WD_DBETA] : 0.0, bnew = found ? sh.fd[WD_BNEW] : 0.0;
@@ -1670,7 +1672,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         batch_pivots(seq, Cn, Sn);
         Sx = Sn;
         C = Cn;
-        if (tid == 0) p.progress[0] = (n_rounds << 8) | 6u;
+        if (DBG && tid == 0) p.progress[0] = (n_rounds << 8) | 6u;
         fold_pass(); // dots of the refills that have arrived meanwhile (off the chain: the streaming workgroups are busy with the message)
         // fired pivots are on record only while a column streamed before their update is still without its dot: positions in front of
         // F all have theirs, and the batches behind are in position order
