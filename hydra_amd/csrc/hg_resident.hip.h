@@ -120,17 +120,19 @@ struct ResParams {
 // Resident mailbox of a rank, written by its peers with system-scope 8-byte stores (xGMI; uncached memory).  Indexed by the SENDER's rank:
 //   gbox[src][parity][RS_BMAX] u64   sweep_id << 48 | n << 24 | the sender's sum over its workgroups of the Gram terms of event n (parity n & 1):
 //                                    self-validating words, no flag
-//   rbox[src][RX_RING][2] u64        the sender's sum of the raw dots (fixed point, 64 bits) of position p, at p mod RX_RING, as two
+//   (build MISS: gbox holds two words per column, tag << 32 | half of the sender's 56-bit fixed-point four-term sum, tag = 1 | sweep | event;
+//    rbox two more words per position for R, the sum over the column's missing calls)
+//   rbox[src][RX_RING][4] u64        the sender's sum of the raw dots (fixed point, 64 bits) of position p, at p mod RX_RING, as two
 //                                    words tag << 32 | low half, tag << 32 | high half with tag = 1 (never the zero of fresh memory) | sweep (11 bits) | the position's refill batch (20)
 // Every word says itself what it is: no flag has to be ordered behind the data (one hop; the reader polls the words it needs).
 // A peer is never more than one event ahead (it needs this rank's part of event n + 1 to get past it) nor more than a window's
 // worth of positions (a position's dot needs every rank's part): two parities and a ring of four windows are enough.
 constexpr uint32_t RX_RING = 1024;
 constexpr size_t RX_GBOX = 0;
-constexpr size_t RX_RBOX = RX_GBOX + (size_t)RX_MAXR * 2 * RS_BMAX * 8;
-constexpr size_t RX_BYTES = RX_RBOX + (size_t)RX_MAXR * RX_RING * 16;
-__device__ __forceinline__ unsigned long long* rx_gbox(unsigned char* mb, int src, uint32_t par) { return reinterpret_cast<unsigned long long*>(mb + RX_GBOX) + ((size_t)src * 2 + par) * RS_BMAX; }
-__device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_RBOX) + (size_t)src * RX_RING * 2; }
+constexpr size_t RX_RBOX = RX_GBOX + (size_t)RX_MAXR * 2 * RS_BMAX * 16;
+constexpr size_t RX_BYTES = RX_RBOX + (size_t)RX_MAXR * RX_RING * 32;
+__device__ __forceinline__ unsigned long long* rx_gbox(unsigned char* mb, int src, uint32_t par) { return reinterpret_cast<unsigned long long*>(mb + RX_GBOX) + ((size_t)src * 2 + par) * RS_BMAX * 2; } // two words per column (build MISS uses both)
+__device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_RBOX) + (size_t)src * RX_RING * 4; } // four words per position: the halves of s1 and (build MISS) of R
 __device__ __forceinline__ unsigned long long rx_rtag(unsigned long long sweep, uint32_t batch) { return (0x80000000ull | ((sweep & 0x7ffull) << 20) | (unsigned long long)(batch & 0xfffffu)) << 32; }
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -838,6 +840,7 @@ struct WalkShared {
     double *gsum, *nmis;       // [B] build MISS: the column's sum of genotypes n1 + 2 n2 and its number of missing calls (all ranks)
     unsigned long long* rprev2; // [RS_RB] build MISS: rprev for the sums over the missing calls
     unsigned long long* gpart64; // [RS_NSH][RS_BMAX] build MISS: gpart for the 8-byte words
+    unsigned long long* rloc2; // [B] several ranks, build MISS: the same for R
     unsigned long long* rloc; // [B] several ranks: this rank's part of the slot's raw dot (pushed to the peers; the dot needs theirs)
     uint8_t* fpush;           // [B] ... has been taken and pushed
     unsigned char* end;
@@ -866,6 +869,7 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.pf_val = reinterpret_cast<double*>(q); q += (size_t)RS_PFIRE * 3 * 8;
     s.ebn = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.rloc = reinterpret_cast<unsigned long long*>(q); q += (size_t)B * 8;
+    s.rloc2 = reinterpret_cast<unsigned long long*>(q); q += (size_t)B * 8;
     s.gsum = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.nmis = reinterpret_cast<double*>(q); q += (size_t)B * 8;
     s.rprev2 = reinterpret_cast<unsigned long long*>(q); q += (size_t)RS_RB * 8;
@@ -1067,14 +1071,35 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             atomicMin(&sh.fl[WF_FMIN], j);
             return;
         }
-        unsigned long long tot;
+        unsigned long long tot, totR = 0ull;
         if (p.nranks > 1) { // this rank's part was taken by push_raw (same thread, same pass); the peers' parts: two self-validating words each
             const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
+            if constexpr (MISS) { // (the peers' parts of R first: the four words of a position are checked together)
+                unsigned long long o2[RX_MAXR][2];
+#pragma unroll
+                for (int r = 0; r < RX_MAXR; ++r) {
+                    const bool on = r < p.nranks && r != p.rank;
+                    const unsigned long long* w = rx_rbox(p.mbox[p.rank], on ? r : p.rank) + 4u * (j % RX_RING) + 2u;
+                    o2[r][0] = on ? __hip_atomic_load(w, HG_RLX_SYSTEM) : tag;
+                    o2[r][1] = on ? __hip_atomic_load(w + 1, HG_RLX_SYSTEM) : tag;
+                }
+                bool all2 = true;
+                totR = sh.rloc2[slot];
+#pragma unroll
+                for (int r = 0; r < RX_MAXR; ++r) {
+                    all2 = all2 && (o2[r][0] >> 32) == (tag >> 32) && (o2[r][1] >> 32) == (tag >> 32);
+                    totR += (o2[r][1] << 32) | (o2[r][0] & 0xffffffffull);
+                }
+                if (!all2) {
+                    atomicMin(&sh.fl[WF_FMIN], j);
+                    return;
+                }
+            }
             unsigned long long o[RX_MAXR][2];
 #pragma unroll
             for (int r = 0; r < RX_MAXR; ++r) {
                 const bool on = r < p.nranks && r != p.rank;
-                const unsigned long long* w = rx_rbox(p.mbox[p.rank], on ? r : p.rank) + 2u * (j % RX_RING);
+                const unsigned long long* w = rx_rbox(p.mbox[p.rank], on ? r : p.rank) + 4u * (j % RX_RING);
                 o[r][0] = on ? __hip_atomic_load(w, HG_RLX_SYSTEM) : tag;
                 o[r][1] = on ? __hip_atomic_load(w + 1, HG_RLX_SYSTEM) : tag;
             }
@@ -1102,7 +1127,9 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         }
         const double s1 = (double)(long long)tot * p.fx_unscale;
         double s2 = p.eps_sum;
-        if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R (single rank: resident_plan)
+        if (MISS && p.nranks > 1) {
+            s2 -= (double)(long long)totR * p.fx_unscale;
+        } else if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R
             unsigned long long* base2 = p.racc2 + (j % RS_RB);
             unsigned long long w2[RS_RSH];
 #pragma unroll
@@ -1152,12 +1179,29 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         const unsigned long long tot = now - sh.rprev[j % RS_RB];
         sh.rprev[j % RS_RB] = now;
         sh.rloc[slot] = tot;
+        unsigned long long tot2 = 0ull;
+        if constexpr (MISS) {
+            unsigned long long* base2 = p.racc2 + (j % RS_RB);
+            unsigned long long w2[RS_RSH];
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) w2[s] = (uint32_t)s < p.rsh ? __hip_atomic_load(base2 + (size_t)s * RS_RB, HG_RLX_AGENT) : 0ull;
+            unsigned long long now2 = 0ull;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
+            tot2 = now2 - sh.rprev2[j % RS_RB];
+            sh.rprev2[j % RS_RB] = now2;
+            sh.rloc2[slot] = tot2;
+        }
         const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
         for (int r = 0; r < p.nranks; ++r)
             if (r != p.rank) {
-                unsigned long long* w = rx_rbox(p.mbox[r], p.rank) + 2u * (j % RX_RING);
+                unsigned long long* w = rx_rbox(p.mbox[r], p.rank) + 4u * (j % RX_RING);
                 __hip_atomic_store(w, tag | (tot & 0xffffffffull), HG_RLX_SYSTEM);
                 __hip_atomic_store(w + 1, tag | (tot >> 32), HG_RLX_SYSTEM);
+                if constexpr (MISS) {
+                    __hip_atomic_store(w + 2, tag | (tot2 & 0xffffffffull), HG_RLX_SYSTEM);
+                    __hip_atomic_store(w + 3, tag | (tot2 >> 32), HG_RLX_SYSTEM);
+                }
             }
         sh.fpush[slot] = 1;
     };
@@ -1226,6 +1270,43 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             if ((uint32_t)tid < gV) {
                 unsigned long long A = 0ull;
                 for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart64[sidx * RS_BMAX + (uint32_t)tid];
+                if (p.nranks > 1) {
+                    // several ranks: the 56-bit sums cross as two words each, tag << 32 | half (tag = 1 | sweep | event: self-validating)
+                    const unsigned long long tag = (0x80000000ull | ((p.sweep_id & 0x7full) << 24) | (unsigned long long)(nev & 0xffffffu)) << 32;
+                    for (int r = 0; r < p.nranks; ++r)
+                        if (r != p.rank) {
+                            unsigned long long* w = rx_gbox(p.mbox[r], p.rank, par) + 2 * tid;
+                            __hip_atomic_store(w, tag | (A & 0xffffffffull), HG_RLX_SYSTEM);
+                            __hip_atomic_store(w + 1, tag | (A >> 32), HG_RLX_SYSTEM);
+                        }
+                    const unsigned long long t0 = wall_clock64();
+                    for (;;) {
+                        unsigned long long o[RX_MAXR][2];
+#pragma unroll
+                        for (int r = 0; r < RX_MAXR; ++r) {
+                            const bool on = r < p.nranks && r != p.rank;
+                            const unsigned long long* w = rx_gbox(p.mbox[p.rank], on ? r : p.rank, par) + 2 * tid;
+                            o[r][0] = on ? __hip_atomic_load(w, HG_RLX_SYSTEM) : tag;
+                            o[r][1] = on ? __hip_atomic_load(w + 1, HG_RLX_SYSTEM) : tag;
+                        }
+                        bool all = true;
+                        unsigned long long add = 0ull;
+#pragma unroll
+                        for (int r = 0; r < RX_MAXR; ++r) {
+                            all = all && (o[r][0] >> 32) == (tag >> 32) && (o[r][1] >> 32) == (tag >> 32);
+                            add += (o[r][1] << 32) | (o[r][0] & 0xffffffffull);
+                        }
+                        if (all) {
+                            A += add;
+                            break;
+                        }
+                        if (wall_clock64() - t0 > p.timeout) {
+                            sh.fl[WF_ABORT] = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 const uint32_t slot = (gq + 1u + (uint32_t)tid) & bmask;
                 const double mj = sh.mave[slot], sj = sh.mstd[slot];
                 const double Ad = (double)A * (1.0 / (double)(1ull << RS_GFX));
@@ -1276,13 +1357,13 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                 const unsigned long long tag = (p.sweep_id << 48) | ((unsigned long long)(nev & 0xffffffu) << 24);
                 if ((uint32_t)tid < gV) {
                     for (int r = 0; r < p.nranks; ++r)
-                        if (r != p.rank) __hip_atomic_store(rx_gbox(p.mbox[r], p.rank, par) + tid, tag | (unsigned long long)A, HG_RLX_SYSTEM);
+                        if (r != p.rank) __hip_atomic_store(rx_gbox(p.mbox[r], p.rank, par) + 2 * tid, tag | (unsigned long long)A, HG_RLX_SYSTEM);
                     const unsigned long long t0 = wall_clock64();
                     for (;;) {
                         unsigned long long o[RX_MAXR];
 #pragma unroll
                         for (int r = 0; r < RX_MAXR; ++r)
-                            o[r] = (r < p.nranks && r != p.rank) ? __hip_atomic_load(rx_gbox(p.mbox[p.rank], r, par) + tid, HG_RLX_SYSTEM) : tag;
+                            o[r] = (r < p.nranks && r != p.rank) ? __hip_atomic_load(rx_gbox(p.mbox[p.rank], r, par) + 2 * tid, HG_RLX_SYSTEM) : tag;
                         bool all = true;
                         uint32_t add = 0u;
 #pragma unroll

@@ -1244,7 +1244,6 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     if (h->nranks > 1 && !(h->p2p_ready && h->p2p_enabled)) return "several ranks without peer mailboxes (hgibbs_p2p_import): the RCCL / host exchange lives in the batch engine";
     if (h->nranks > RX_MAXR) return "more than eight ranks";
     if (h->force_split) return "force_split";
-    if (h->any_missing && h->nranks > 1) return "columns with missing calls on several ranks (their four-term Gram sums have no cross-rank exchange)";
     if (h->G * h->K > 256 || h->K > MAX_K || h->K < 2) return "mixture size";
     const uint32_t cus = h->res_cus ? std::min<uint32_t>(h->res_cus, (uint32_t)h->num_cu) : (uint32_t)h->num_cu;
     if (cus < 2) return "fewer than two compute units";

@@ -111,9 +111,10 @@ def test_two_ranks_one_gpu_p2p_exchange(batch, M, N, world, miss):
     assert res[0][6] == ch.last_nnz()
 
 
-@pytest.mark.parametrize("M,N,world,opts,iters", [(400, 9000, 2, {}, 3), (500, 21000, 3, {"window": 64}, 3), (300, 30000, 2, {"res_cus": 9}, 3),
-                                                  (2500, 70000, 2, {}, 8)])
-def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts, iters):
+@pytest.mark.parametrize("M,N,world,opts,iters,miss", [(400, 9000, 2, {}, 3, 0.0), (500, 21000, 3, {"window": 64}, 3, 0.0), (300, 30000, 2, {"res_cus": 9}, 3, 0.0),
+                                                       (2500, 70000, 2, {}, 8, 0.0), (400, 9000, 2, {}, 4, 0.02), (500, 21000, 3, {"window": 64}, 3, 0.01),
+                                                       (300, 30000, 2, {"res_cus": 9}, 3, 0.05)])
+def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts, iters, miss):
     """The resident engine sharded over ranks (here: processes that share device 0; the mailboxes are IPC-mapped memory as between
     GPUs): every rank runs one resident kernel on its shard, the walkers are replicas that add the peers' integer Gram sums and
     fixed-point raw dots from their mailboxes.  Replicas bit-identical; equal to the CPU oracle's chain on the whole data
@@ -121,7 +122,7 @@ def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts, iters):
     import torch.multiprocessing as mp
     import orc
     from hydra_amd import synth
-    geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.0)
+    geno = synth.make_genotypes(M, N, seed=71, missing_rate=miss)  # (missing calls: the build with s2 per column and four-term Gram sums, both exchanged)
     y, _ = synth.make_phenotype(geno, seed=72, causal_frac=0.05)
     bed = synth.pack_bed_columns(geno)
     ctx = mp.get_context("spawn")
