@@ -3,7 +3,7 @@
 Every variant must walk the same chain (components exact, beta to 1e-9 of the plain path's): the variants differ in what
 runs concurrently inside a launch (carried columns / Gram-only groups, the ahead queue, slices, segments), so a rare
 ordering bug in the hand-offs would show as a divergence at some iteration.
-usage: soak.py [N] [M] [iterations] [missing rate]"""
+usage: soak.py [N] [M] [iterations] [missing rate]   (SOAK_VARIANTS=plain,resident keeps the variants whose name contains one of the words)"""
 import sys
 import os
 import time
@@ -26,6 +26,9 @@ VARIANTS = [("plain: gram=0, batch 200", {"gram": 0, "batch": 200}),
             ("carry on, ahead 64", {"carry": 1, "ahead": 64}),
             ("four segments, carry on, ahead 128", {"max_seg": 4, "carry": 1, "ahead": 128}),
             ("8 slices, cols_per_group 8", {"slices": 8, "cols_per_group": 8})]
+if os.environ.get("SOAK_VARIANTS"):  # comma-separated substrings of the variant names to keep (the first one kept is the reference)
+    keep = [w.strip() for w in os.environ["SOAK_VARIANTS"].split(",") if w.strip()]
+    VARIANTS = [v for v in VARIANTS if any(w in v[0] for w in keep)]
 devs = []
 for name, opts in VARIANTS:
     dev = capi.Device(0)
