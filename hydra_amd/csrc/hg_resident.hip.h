@@ -16,11 +16,14 @@
 //     event, draws its effect (a5-a7) and broadcasts (position, dbeta) as one 16-byte message.
 //
 // Per event one round: message -> [eps update | Gram terms of the window -> atomics | dots of the columns that refill
-// the window -> atomics] -> walker.  The only cross-CU traffic of a round is ~V + 2 * ncons 8-byte atomic adds per
-// workgroup and one 16-byte message.  Sums over workgroups are integers (the Gram terms; the raw dots as 62-bit
-// fixed point), accumulated by memory-side atomic adds into words that carry their own arrival count in the top 16
-// bits: exact, order-independent (the chain does not depend on the launch geometry) and self-validating (no flag, no
-// fence).  Every spin is bounded (ResParams::timeout): a lost peer ends the sweep with error 3, never a hang.
+// the window -> atomics] -> walker.  The only cross-CU traffic of a round is one 4-byte atomic add per window column and
+// one 8-byte add per refilled column from every workgroup, and one 16-byte message.  Sums over workgroups are integers (the
+// Gram terms; the raw dots as 51-bit fixed point), accumulated by memory-side atomic adds: exact and order-independent
+// (the chain does not depend on the launch geometry).  The Gram words carry their own arrival count in the top byte, the
+// raw dots a count of completed refill batches; nothing is ever stored to an accumulator (the walker takes differences to
+// what it saw last).  Every spin is bounded (ResParams::timeout): a lost peer ends the sweep with error 3, never a hang.
+// Builds: T = 1, 2 wave tiles per workgroup; DBG stage clocks; MISS columns with missing calls (s2 per column, four-term
+// Gram sums).  Several ranks (GPUs): one such kernel per rank, replica walkers, sums exchanged through peer mailboxes (RX_*).
 #pragma once
 
 #include "hg_sweep.hip.h"
@@ -179,24 +182,6 @@ __host__ __device__ inline size_t rs_streamer_lds_miss(uint32_t B, int T)
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
 // ---------------------------------------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void rs_load_col(const uint8_t* col, uint32_t voff, uint32_t (&w)[T])
-{
-    if constexpr (T == 1) {
-        w[0] = *reinterpret_cast<const uint32_t*>(col + voff);
-    } else if constexpr (T == 2) {
-        const uint2 v = *reinterpret_cast<const uint2*>(col + voff);
-        w[0] = v.x;
-        w[1] = v.y;
-    } else {
-        const uint4 v = *reinterpret_cast<const uint4*>(col + voff);
-        w[0] = v.x;
-        w[1] = v.y;
-        w[2] = v.z;
-        w[3] = v.w;
-    }
-}
-
 // The refill's columns land in the TOP 32 vector registers, named by hand: v224 .. v255 are outside what the compiler may allocate
 // (the kernel carries amdgpu_num_vgpr(RS_VGPR_LIMIT)), so nothing but the instructions below ever touches them.  The loads are
 // instructions the compiler does not see as loads: it would otherwise place its own wait before the first use of a loaded register,
