@@ -255,6 +255,34 @@ __device__ __forceinline__ int32_t rs_lane_ids()
     return v;
 }
 
+// The 64-lane sums of sixteen accumulators, each a pair of 16-bit column sums, scattered: lane c < 32 gets the sum of column c
+// (accumulator c >> 1, half c & 1).  A reduce-scatter -- at every step a lane keeps the half of its values that matches its
+// next lane bit and adds its partner's -- costs ~60 instructions instead of the ~180 of sixteen separate wave sums: after four
+// DPP steps (lane ^ 1, ^ 2, ^ 4, ^ 8; the last two as two mirrors each) lane l holds its row's sum of accumulator l & 15, two
+// crossbar steps add the four rows, one more brings accumulator c >> 1 to lane c.
+__device__ __forceinline__ uint32_t wave_sum16_scatter(const uint32_t (&acc)[16], int lane)
+{
+    auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, false); };
+    using QX1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]: lane ^ 1
+    using QX2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]: lane ^ 2
+    using QX3 = std::integral_constant<int, 0x1B>;  // quad_perm [3,2,1,0]: lane ^ 3
+    using HM = std::integral_constant<int, 0x141>;  // row_half_mirror: lane ^ 7
+    using RM = std::integral_constant<int, 0x140>;  // row_mirror: lane ^ 15
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    uint32_t b[8], c[4], d[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (b0 ? acc[2 * i + 1] : acc[2 * i]) + dpp(b0 ? acc[2 * i] : acc[2 * i + 1], QX1{});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + dpp(b1 ? b[2 * i] : b[2 * i + 1], QX2{});
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d[i] = (b2 ? c[2 * i + 1] : c[2 * i]) + dpp(dpp(b2 ? c[2 * i] : c[2 * i + 1], QX3{}), HM{}); // ^ 3 then ^ 7 = ^ 4
+    uint32_t v = (b3 ? d[1] : d[0]) + dpp(dpp(b3 ? d[0] : d[1], HM{}), RM{});                                                    // ^ 7 then ^ 15 = ^ 8
+    v += (uint32_t)__shfl_xor((int)v, 16, 64);
+    v += (uint32_t)__shfl_xor((int)v, 32, 64); // every lane: the wave's sum of accumulator lane & 15
+    const uint32_t w = (uint32_t)__shfl((int)v, lane >> 1, 64);
+    return (lane & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
 // four 64-lane integer sums at once (hg_sweep.hip.h: wave_sum_u32), step by step over the four: totals returned wave-uniform
 __device__ __forceinline__ void wave_sum_u32x4(uint32_t (&v)[4])
 {
@@ -544,18 +572,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                     }
                 }
             }
-            // wave sums of the packed accumulators, four at a time: a sum is a chain of six dependent DPP steps (~20 clocks each), four
-            // independent chains share the waiting
-            uint32_t mine = 0u;
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 4) {
-                if ((uint32_t)(2 * r0) < Vw) { // wave-uniform
-                    uint32_t tot[4] = {acc[r0], acc[r0 + 1], acc[r0 + 2], acc[r0 + 3]};
-                    wave_sum_u32x4(tot);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) mine = (lane == 2 * (r0 + k)) ? (tot[k] & 0xffffu) : ((lane == 2 * (r0 + k) + 1) ? (tot[k] >> 16) : mine);
-                }
-            }
+            const uint32_t mine = wave_sum16_scatter(acc, lane); // lane c: the wave's Gram term of its column c
             if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words: count in the top byte
                 __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
             }
