@@ -260,7 +260,7 @@ __device__ __forceinline__ int32_t rs_lane_ids()
 // next lane bit and adds its partner's -- costs ~60 instructions instead of the ~180 of sixteen separate wave sums: after four
 // DPP steps (lane ^ 1, ^ 2, ^ 4, ^ 8; the last two as two mirrors each) lane l holds its row's sum of accumulator l & 15, two
 // crossbar steps add the four rows, one more brings accumulator c >> 1 to lane c.
-__device__ __forceinline__ uint32_t wave_sum16_scatter(const uint32_t (&acc)[16], int lane)
+__device__ __forceinline__ uint32_t wave_sum16_rows(const uint32_t (&acc)[16], int lane)
 {
     auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, false); };
     using QX1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]: lane ^ 1
@@ -278,8 +278,12 @@ __device__ __forceinline__ uint32_t wave_sum16_scatter(const uint32_t (&acc)[16]
     for (int i = 0; i < 2; ++i) d[i] = (b2 ? c[2 * i + 1] : c[2 * i]) + dpp(dpp(b2 ? c[2 * i] : c[2 * i + 1], QX3{}), HM{}); // ^ 3 then ^ 7 = ^ 4
     uint32_t v = (b3 ? d[1] : d[0]) + dpp(dpp(b3 ? d[0] : d[1], HM{}), RM{});                                                    // ^ 7 then ^ 15 = ^ 8
     v += (uint32_t)__shfl_xor((int)v, 16, 64);
-    v += (uint32_t)__shfl_xor((int)v, 32, 64); // every lane: the wave's sum of accumulator lane & 15
-    const uint32_t w = (uint32_t)__shfl((int)v, lane >> 1, 64);
+    v += (uint32_t)__shfl_xor((int)v, 32, 64);
+    return v; // every lane: the wave's sum of accumulator lane & 15
+}
+__device__ __forceinline__ uint32_t wave_sum16_scatter(const uint32_t (&acc)[16], int lane)
+{
+    const uint32_t w = (uint32_t)__shfl((int)wave_sum16_rows(acc, lane), lane >> 1, 64);
     return (lane & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
@@ -500,18 +504,15 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 }
                 const double mqv = mq.x;
                 // the four integer sums of a column meet packed (A | P << 16, Q | X << 16: a lane adds at most 128 / 64 / 64 / 32, the wave
-                // 8192 / 4096 / 4096 / 2048), four columns' wave sums at a time; lane c then holds column c's totals and forms its term
-                uint32_t ap_mine = 0u, qx_mine = 0u;
-                double mj_mine = 0.0;
-                for (uint32_t c0 = 0; c0 < Vw; c0 += 4u) { // wave-uniform
-                    uint32_t ap[4], qx[4];
-                    double mjs[4];
+                // 8192 / 4096 / 4096 / 2048), sixteen columns to a reduce-scatter: lane c < 16 then holds column c0 + c's totals, forms its
+                // term and sends it
+                for (uint32_t c0 = 0; c0 < Vw; c0 += 16u) { // wave-uniform
+                    uint32_t ap[16], qx[16];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 16; ++k) {
                         const uint32_t i = i0 + c0 + (uint32_t)k;
                         const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
                         const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-                        mjs[k] = meta[slot].x;
                         uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
@@ -526,21 +527,15 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         ap[k] = A | (P << 16);
                         qx[k] = Q | (X << 16);
                     }
-                    wave_sum_u32x4(ap);
-                    wave_sum_u32x4(qx);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool me = (uint32_t)lane == c0 + (uint32_t)k;
-                        ap_mine = me ? ap[k] : ap_mine;
-                        qx_mine = me ? qx[k] : qx_mine;
-                        mj_mine = me ? mjs[k] : mj_mine;
+                    const uint32_t apt = wave_sum16_rows(ap, lane), qxt = wave_sum16_rows(qx, lane);
+                    const uint32_t mycol = i0 + c0 + ((uint32_t)lane & 15u);
+                    if ((uint32_t)lane < 16u && c0 + (uint32_t)lane < Vw && mycol < V) {
+                        const double mj = meta[(q + 1u + mycol) & bmask].x;
+                        const double mine = ((double)(apt & 0xffffu) + mqv * (double)(apt >> 16)) + (mj * (double)(qxt & 0xffffu) + (mj * mqv) * (double)(qxt >> 16));
+                        const double MAGIC = 6755399441055744.0;
+                        const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
+                        __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + mycol, RS_ONE64 | fx, HG_RLX_AGENT);
                     }
-                }
-                const double mine = ((double)(ap_mine & 0xffffu) + mqv * (double)(ap_mine >> 16)) + (mj_mine * (double)(qx_mine & 0xffffu) + (mj_mine * mqv) * (double)(qx_mine >> 16));
-                if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) {
-                    const double MAGIC = 6755399441055744.0;
-                    const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
-                    __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE64 | fx, HG_RLX_AGENT);
                 }
             }
             } else
