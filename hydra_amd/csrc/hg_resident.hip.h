@@ -682,9 +682,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         // the first RS_PMAX of them in the window as it stands now, [Cn, Sn), are this batch's pivots, and every column of the batch
         // behind one of them takes its integer Gram term with it here, where both columns are in LDS -- the walker then needs no
         // round trip when that pivot's turn comes (message RS_PIVOT).  Wave 0 finds the pivots, in position order.
+        if (p.pivots) { // (uniform; without the option the round goes straight from the refill's barrier to the finishing threads)
         if (tid < WAVE) {
             uint32_t np = 0;
-            for (uint32_t b0 = Cn; p.pivots && b0 < Sn && np < (uint32_t)RS_PMAX; b0 += WAVE) {
+            for (uint32_t b0 = Cn; b0 < Sn && np < (uint32_t)RS_PMAX; b0 += WAVE) {
                 const uint32_t pp = b0 + (uint32_t)lane;
                 unsigned long long m = __ballot(pp < Sn && pflag[pp & bmask] != 0);
                 while (m && np < (uint32_t)RS_PMAX) {
@@ -720,6 +721,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         // One thread per refilled position adds the eight group sums of its column in order and sends the workgroup's part of s1 as
         // a 51-bit fixed-point integer -- taken from "x + 1.5 2^52" (round to nearest, exact for |x| < 2^51) -- by an 8-byte atomic add
         // (contiguous over the threads: one 64-byte request per eight positions): sums over workgroups are exact and do not depend on
@@ -744,7 +746,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
-            const uint32_t np = pivl[0];
+            const uint32_t np = p.pivots ? pivl[0] : 0u;
             for (uint32_t ip = 0; ip < np; ++ip)
                 if (pivl[1 + ip] < Sx + t)
                     __hip_atomic_fetch_add(p.pacc + ((size_t)(wg % p.rsh) * RS_PMAX + ip) * RS_RB + ((Sx + t) % RS_RB), pterm[t * (uint32_t)RS_PMAX + ip], HG_RLX_AGENT);
