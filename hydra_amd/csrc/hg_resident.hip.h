@@ -102,7 +102,8 @@ struct ResParams {
     unsigned long long* racc2; // [RS_RSH][RS_RB] (build MISS): the same for R = sum of eps over the column's missing calls (s2 = sum of eps - R)
     unsigned long long* gacc64; // [2][RS_NSH] rows of RS_GROW 8-byte words (build MISS): count << 56 | fixed-point sum of the workgroups' four-term Gram sums
     const unsigned long long* counts; // [M][3] (n1, n2, missing) by marker, summed over the ranks
-    uint32_t* pacc;           // [RS_RSH][RS_PMAX][RS_RB]: sum of the workgroups' Gram terms of position p (at p mod RS_RB) with its batch's pivots
+    unsigned long long* pacc; // [RS_RSH][RS_RB][2]: sums of the workgroups' Gram terms of position p (at p mod RS_RB) with its batch's pivots, two 32-bit
+                              // fields to a word (pivots 0 | 1 << 32, 2 | 3 << 32: a batch adds < 2^32 to a field, and the walker decodes DIFFERENCES)
     ResMsg* msg;              // [RS_MSG]
     ResState* state;
     double fx_scale, fx_unscale; // raw dots travel as round(dot * fx_scale), |.| < 2^51 per workgroup
@@ -747,9 +748,18 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
             const uint32_t np = p.pivots ? pivl[0] : 0u;
-            for (uint32_t ip = 0; ip < np; ++ip)
-                if (pivl[1 + ip] < Sx + t)
-                    __hip_atomic_fetch_add(p.pacc + ((size_t)(wg % p.rsh) * RS_PMAX + ip) * RS_RB + ((Sx + t) % RS_RB), pterm[t * (uint32_t)RS_PMAX + ip], HG_RLX_AGENT);
+            if (np) {
+                unsigned long long w01 = 0ull, w23 = 0ull;
+                for (uint32_t ip = 0; ip < np; ++ip)
+                    if (pivl[1 + ip] < Sx + t) {
+                        const unsigned long long v = (unsigned long long)pterm[t * (uint32_t)RS_PMAX + ip] << (32u * (ip & 1u));
+                        if (ip < 2u) w01 += v;
+                        else w23 += v;
+                    }
+                unsigned long long* pw = p.pacc + ((size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB)) * 2u;
+                if (w01) __hip_atomic_fetch_add(pw, w01, HG_RLX_AGENT);
+                if (w23) __hip_atomic_fetch_add(pw + 1, w23, HG_RLX_AGENT);
+            }
         }
         wait_vmcnt<0>();
         lap(5);
@@ -828,7 +838,7 @@ struct WalkShared {
     uint32_t* bl_pos; // [RS_NB][RS_PMAX] the pivots of a refill batch (positions, in order), by batch number mod RS_NB
     uint8_t* bl_np;   // [RS_NB] how many
     uint32_t* w_pt;   // [B][RS_PMAX] window slot: its column's Gram terms with its batch's pivots (those in front of it)
-    uint32_t* pprev;  // [RS_PMAX][RS_RB] sum over the shards of the pivot-term words as last seen
+    unsigned long long* pprev; // [2][RS_RB] sum over the shards of the two pivot-term words as last seen
     uint32_t* pf_pos; // [RS_PFIRE] pivots that fired while columns streamed before their update were still without their dot:
     uint32_t* pf_msg; //            position, message number, then (dbeta, mave, mstd)
     double* pf_val;   // [RS_PFIRE][3]
@@ -886,7 +896,7 @@ __host__ __device__ inline WalkShared walk_carve(unsigned char* q, uint32_t B)
     s.lcass = reinterpret_cast<int32_t*>(q); q += 256 * 4;
     s.bl_pos = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_NB * RS_PMAX * 4;
     s.w_pt = reinterpret_cast<uint32_t*>(q); q += (size_t)B * RS_PMAX * 4;
-    s.pprev = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PMAX * RS_RB * 4;
+    s.pprev = reinterpret_cast<unsigned long long*>(q); q += (size_t)2 * RS_RB * 8;
     s.pf_pos = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PFIRE * 4;
     s.pf_msg = reinterpret_cast<uint32_t*>(q); q += (size_t)RS_PFIRE * 4;
     s.crank = reinterpret_cast<uint16_t*>(q); q += (size_t)RS_BMAX * 2;
@@ -958,7 +968,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         sh.rprev[i] = 0ull;
         sh.rprev2[i] = 0ull;
     }
-    for (int i = tid; i < RS_PMAX * RS_RB; i += RS_BLOCK) sh.pprev[i] = 0u;
+    for (int i = tid; i < 2 * RS_RB; i += RS_BLOCK) sh.pprev[i] = 0ull;
     if (tid < 64) sh.fl[tid] = 0u;
     auto tabv = [&](int which, int t) -> double { // 0 denom, 1 logpi, 2 hlog, 3 sdk
         if (lds_tab) return sh.htab[which * HT_LDS + t];
@@ -1145,12 +1155,27 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         // the column was streamed
         const uint32_t bt = sh.batch[slot], np = sh.bl_np[bt % RS_NB];
         const uint32_t* bp = sh.bl_pos + (bt % RS_NB) * RS_PMAX;
-        for (uint32_t ip = 0; ip < np; ++ip) {
-            if (bp[ip] >= j) break;
-            uint32_t nowp = 0u;
-            for (uint32_t sidx = 0; sidx < p.rsh; ++sidx) nowp += __hip_atomic_load(p.pacc + ((size_t)sidx * RS_PMAX + ip) * RS_RB + (j % RS_RB), HG_RLX_AGENT);
-            sh.w_pt[slot * RS_PMAX + ip] = nowp - sh.pprev[ip * RS_RB + (j % RS_RB)];
-            sh.pprev[ip * RS_RB + (j % RS_RB)] = nowp;
+        if (np && bp[0] < j) { // (a pivot in front of the column: its terms were sent; all shards' two words at once, the batch's part = the difference)
+            unsigned long long w[RS_RSH][2];
+#pragma unroll
+            for (int sidx = 0; sidx < RS_RSH; ++sidx) {
+                const unsigned long long* pw = p.pacc + ((size_t)((uint32_t)sidx < p.rsh ? sidx : 0) * RS_RB + (j % RS_RB)) * 2u;
+                w[sidx][0] = (uint32_t)sidx < p.rsh ? __hip_atomic_load(pw, HG_RLX_AGENT) : 0ull;
+                w[sidx][1] = (uint32_t)sidx < p.rsh ? __hip_atomic_load(pw + 1, HG_RLX_AGENT) : 0ull;
+            }
+            unsigned long long n01 = 0ull, n23 = 0ull;
+#pragma unroll
+            for (int sidx = 0; sidx < RS_RSH; ++sidx) {
+                n01 += w[sidx][0];
+                n23 += w[sidx][1];
+            }
+            const unsigned long long d01 = n01 - sh.pprev[j % RS_RB], d23 = n23 - sh.pprev[RS_RB + (j % RS_RB)];
+            sh.pprev[j % RS_RB] = n01;
+            sh.pprev[RS_RB + (j % RS_RB)] = n23;
+            sh.w_pt[slot * RS_PMAX + 0] = (uint32_t)d01;
+            sh.w_pt[slot * RS_PMAX + 1] = (uint32_t)(d01 >> 32);
+            sh.w_pt[slot * RS_PMAX + 2] = (uint32_t)d23;
+            sh.w_pt[slot * RS_PMAX + 3] = (uint32_t)(d23 >> 32);
         }
         for (uint32_t f = 0; f < pf_n; ++f) {
             const uint32_t fq = sh.pf_pos[f];

@@ -177,7 +177,7 @@ static int ensure_scratch(hgibbs_ctx* h, size_t n)
     return 0;
 }
 
-static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4, RES_PACC_BYTES = (size_t)RS_RSH * RS_PMAX * RS_RB * 4;
+static constexpr size_t RES_GACC_BYTES = (size_t)2 * RS_NSH * RS_GROW * 4, RES_RACC_BYTES = (size_t)RS_RSH * RS_RB * 8, RES_RCNT_BYTES = (size_t)RS_RSH * RS_CROW * 4, RES_PACC_BYTES = (size_t)RS_RSH * RS_RB * 2 * 8;
 static constexpr size_t RES_RACC2_OFF = RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES + RES_PACC_BYTES, RES_GACC64_BYTES = (size_t)2 * RS_NSH * RS_GROW * 8;
 static constexpr size_t RES_ACC_BYTES = RES_RACC2_OFF + RES_RACC_BYTES + RES_GACC64_BYTES; // (+ the MISS build's second raw sums and its 8-byte Gram words)
 static constexpr size_t MBOX_DATA_BYTES = (size_t)2 * MAX_RANKS * ROWS_CAP * sizeof(double);
@@ -1302,7 +1302,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.gacc = reinterpret_cast<uint32_t*>(h->res_acc);
     p.racc = reinterpret_cast<unsigned long long*>(h->res_acc + RES_GACC_BYTES);
     p.rcnt = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES);
-    p.pacc = reinterpret_cast<uint32_t*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES);
+    p.pacc = reinterpret_cast<unsigned long long*>(h->res_acc + RES_GACC_BYTES + RES_RACC_BYTES + RES_RCNT_BYTES);
     p.racc2 = reinterpret_cast<unsigned long long*>(h->res_acc + RES_RACC2_OFF);
     p.gacc64 = reinterpret_cast<unsigned long long*>(h->res_acc + RES_RACC2_OFF + RES_RACC_BYTES);
     p.counts = h->counts;
