@@ -169,16 +169,18 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
     return v;
 }
 
-__host__ __device__ inline size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 97 + (size_t)B * 256 * T; }
+__host__ __device__ constexpr size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 97 + (size_t)B * 256 * T; }
 // build MISS: a copy of the workgroup's eps slice in LDS, addressable by individual ([(16 t + slot) * 64 + lane] doubles), for the sums
 // over a column's (few) missing calls.  The build keeps two group sums per refilled position instead of eight and no pivot terms: the
 // copy lives in what that frees of the plain layout (between 512 + 32 B and the ring) when it fits there, else behind the ring.
-__host__ __device__ inline size_t rs_epsl_off(uint32_t B, int T) { return ((size_t)B * 65 >= (size_t)8192 * T) ? 512 + (size_t)B * 32 : rs_streamer_lds(B, T); }
-__host__ __device__ inline size_t rs_streamer_lds_miss(uint32_t B, int T)
+__host__ __device__ constexpr size_t rs_epsl_off(uint32_t B, int T) { return ((size_t)B * 65 >= (size_t)8192 * T) ? 512 + (size_t)B * 32 : rs_streamer_lds(B, T); }
+__host__ __device__ constexpr size_t rs_streamer_lds_miss(uint32_t B, int T)
 {
-    const size_t a = rs_streamer_lds(B, T), b = rs_epsl_off(B, T) + (size_t)8192 * T;
-    return a > b ? a : b;
+    return rs_streamer_lds(B, T) > rs_epsl_off(B, T) + (size_t)8192 * T ? rs_streamer_lds(B, T) : rs_epsl_off(B, T) + (size_t)8192 * T;
 }
+static_assert(rs_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds_miss(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds_miss(RS_BMAX, 1) <= 160 * 1024,
+              "the largest window at the most tiles per workgroup fits the 160 KB of LDS of a compute unit, in both builds");
+static_assert(rs_epsl_off(RS_BMAX, RS_TMAX) + (size_t)8192 * RS_TMAX <= 512 + (size_t)RS_BMAX * 97, "there, the LDS copy of eps ends in front of the ring");
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
