@@ -54,12 +54,22 @@ constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marke
 
 enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has); RS_LAST is a flag bit
 
-// tag = seq << 32 | kind << 28 | ncons: the walker consumed `ncons` positions; RS_EVENT: the last of them changed its
+// tag = seq << 32 | kind << 28 | check << 12 | ncons: the walker consumed `ncons` positions; RS_EVENT: the last of them changed its
 // effect by -dbeta (dbeta = old - new)
 struct ResMsg {
     unsigned long long tag;
     double dbeta;
 };
+// A message is ONE 16-byte store and is read by ONE 16-byte load (a single transaction either way on this hardware); the word with
+// kind and count also carries 16 check bits over the other three words, so that a reader that ever saw a torn message would keep
+// polling instead of acting on it.  word 0 = kind << 28 | check << 12 | positions consumed (<= RS_BMAX).
+__host__ __device__ inline uint32_t rs_msg_check(uint32_t seq, uint32_t lo, uint32_t hi)
+{
+    uint32_t x = seq * 0x9E3779B1u ^ lo ^ (hi * 0x85EBCA77u);
+    x ^= x >> 16;
+    return x & 0xffffu;
+}
+__host__ __device__ inline uint32_t rs_msg_word0(uint32_t kf, uint32_t ncons, uint32_t seq, uint32_t lo, uint32_t hi) { return (kf << 28) | (rs_msg_check(seq, lo, hi) << 12) | ncons; }
 
 struct ResState { // device -> host, written by the walker at the end of the sweep
     uint32_t cursor, rng_idx, error, pad;
@@ -783,7 +793,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             u4_t v;
             for (;;) {
                 v = rs_load16(m);
-                if (v.y == seq) break;
+                if (v.y == seq && ((v.x >> 12) & 0xffffu) == rs_msg_check(seq, v.z, v.w)) break;
                 if (wall_clock64() - t0 > p.timeout) {
                     v.x = (uint32_t)RS_ABORT << 28;
                     v.y = seq;
@@ -801,7 +811,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         const uint32_t kf = (uint32_t)(tag >> 28) & 0xfu;
         kind = kf & 7u;
         last = (kf & RS_LAST) != 0u;
-        ncons = (uint32_t)tag & 0x0fffffffu;
+        ncons = (uint32_t)tag & 0xfffu;
         lap(0);
         if (timing) p.trace[4 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         if (kind == RS_ABORT) break;
@@ -1604,7 +1614,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                                     p.trace[3 * RS_TRACE + seq % RS_TRACE] = nc;
                                     p.trace[0 * RS_TRACE + (seq + 1u) % RS_TRACE] = wall_clock64();
                                 }
-                                rs_store16(p.msg + ((seq + 1u) % RS_MSG), rs_u4((kf << 28) | nc, seq + 1u, (uint32_t)db, (uint32_t)(db >> 32)));
+                                rs_store16(p.msg + ((seq + 1u) % RS_MSG), rs_u4(rs_msg_word0(kf, nc, seq + 1u, (uint32_t)db, (uint32_t)(db >> 32)), seq + 1u, (uint32_t)db, (uint32_t)(db >> 32)));
                                 sh.fl[WF_POSTED] = 1u;
                             }
                         } else {
@@ -1693,7 +1703,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         if (tid == 0 && !posted) {
             const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE)) | (lastmsg ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
-            rs_store16(p.msg + (seq % RS_MSG), rs_u4((kf << 28) | ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)));
+            rs_store16(p.msg + (seq % RS_MSG), rs_u4(rs_msg_word0(kf, ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)), seq, (uint32_t)db, (uint32_t)(db >> 32)));
         }
         if (pivot) {
             // corrections of the window columns behind q that have their dot; the others get theirs when it arrives (try_raw)
@@ -1814,7 +1824,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
     if (aborted) {
         ++seq;
         if (tid == 0) {
-            rs_store16(p.msg + (seq % RS_MSG), rs_u4((uint32_t)RS_ABORT << 28, seq, 0u, 0u));
+            rs_store16(p.msg + (seq % RS_MSG), rs_u4(rs_msg_word0((uint32_t)RS_ABORT, 0u, seq, 0u, 0u), seq, 0u, 0u));
             atomicMax(&p.state->error, sh.fl[WF_ERR] ? sh.fl[WF_ERR] : 3u);
         }
     }
