@@ -156,6 +156,9 @@ __device__ __forceinline__ u4_t rs_load16(const void* p)
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// A barrier for what the workgroup shares through LDS only: __syncthreads() also waits for every store to global memory the wave has in
+// flight (results, pushes to the peers' mailboxes: a round trip each) -- for nothing where no other thread of the workgroup reads them.
+__device__ __forceinline__ void rs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void rs_store16(void* p, u4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ double rs_readlane(double v, int l)
 {
@@ -1245,12 +1248,12 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
     auto fold_pass = [&]() {
         refresh_batches();
         if (tid == 0) sh.fl[WF_FMIN] = Sx;
-        __syncthreads();
+        rs_lds_barrier();
         const uint32_t done = sh.fl[WF_RDONE];
         if (p.nranks > 1)
             for (uint32_t j = F + (uint32_t)tid; j < Sx; j += RS_BLOCK) push_raw(j, done);
         for (uint32_t j = F + (uint32_t)tid; j < Sx; j += RS_BLOCK) try_raw(j, done);
-        __syncthreads();
+        rs_lds_barrier(); // (not __syncthreads(): the pushes to the peers need not have arrived)
         F = sh.fl[WF_FMIN];
     };
 
@@ -1774,7 +1777,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             sh.fl[WF_FOUND] = 0u;
             sh.fl[WF_POSTED] = 0u;
         }
-        __syncthreads();
+        rs_lds_barrier(); // (the results above are stores nobody here reads)
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         prefetch(Sx, Sn, seq);
         if (rpos >= (uint32_t)MT_N) { // the stream crossed into the next block: it becomes the current one
@@ -1785,7 +1788,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             rpos -= (uint32_t)MT_N;
             has_next = false;
         }
-        __syncthreads();
+        rs_lds_barrier();
         batch_pivots(seq, Cn, Sn);
         Sx = Sn;
         C = Cn;
