@@ -214,3 +214,21 @@ def test_random_configurations_match_the_oracle(oracle, case):
         opts["pivots"] = 1
     run_vs_oracle(oracle, M, N, iters=4, groups=groups, mS=mS, opts=opts, seed=int(rng.integers(1, 1 << 30)), causal_frac=float(rng.choice([0.01, 0.05, 0.3])),
                   missing_rate=0.03 if missing_cols > 0.0 else 0.0, missing_cols=missing_cols)
+
+
+def test_auto_engine_falls_back_to_the_batch_engine(oracle):
+    """engine = 0 (the default): where the resident engine does not apply -- here one streaming workgroup for six wave tiles --
+    the sweep runs on the batch engine, silently and with the same chain."""
+    M, N = 200, 6000
+    bed, y = make_case(M, N, seed=3)
+    ref = orc.Chain(oracle, bed, N, y, seed=5, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_option("res_cus", 2)
+    ch = capi.Chain(dev, y, seed=5, shuffle=1)
+    for _ in range(3):
+        ref.iterate()
+        ch.iterate()
+        assert dev.sweep_stats()["engine"] == 1
+        beta, comp, _ = dev.get_beta()
+        assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
