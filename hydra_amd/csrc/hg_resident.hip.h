@@ -123,6 +123,8 @@ struct ResParams {
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
+    int walker; // 2: the second walker (hg_walker2.hip.h: one wave walks the chain, the others serve it), else the first
+    const uint32_t* pred; // the sweep positions whose marker has a non-zero effect at sweep start (predicted events), ascending, then 16 sentinels 0xffffffff
     int all_ada; // 1: no marker is frozen out (adaV all ones, the usual case): a marker's uniform is its distance from the cursor
     // several GPUs (individuals sharded over the ranks): every rank runs this kernel on its shard, the walkers are
     // replicas that decide on the SAME integer sums -- each adds its peers' parts, which arrive in its mailbox (RX_* below)
@@ -150,6 +152,7 @@ __device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int sr
 __device__ __forceinline__ unsigned long long rx_rtag(unsigned long long sweep, uint32_t batch) { return (0x80000000ull | ((sweep & 0x7ffull) << 20) | (unsigned long long)(batch & 0xfffffu)) << 32; }
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) uint32_t rs_cu32; // read-only global memory through the scalar cache
 __device__ __forceinline__ u4_t rs_load16(const void* p)
 {
     u4_t v;
@@ -387,9 +390,6 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
     double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
     double* const part = reinterpret_cast<double*>(smem + 512 + (size_t)B * 16);       // this round's refill: [position - Sx][8] sums of the wave's eight-lane groups
-    uint8_t* const pflag = smem + 512 + (size_t)B * 80;                                // window slot: the column is a predicted pivot (effect non-zero at sweep start)
-    uint32_t* const pterm = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 81);  // this round's refill: [position - Sx][RS_PMAX] Gram terms with the batch's pivots
-    uint32_t* const pivl = reinterpret_cast<uint32_t*>(smem + 320);                    // [0] = number of the batch's pivots, [1 ..] their positions
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 97);  // [B][64 * T] codes of the window columns
     double* const epsl = reinterpret_cast<double*>(smem + rs_epsl_off(B, T));           // build MISS: the eps slice by individual (see rs_epsl_off)
     const bool timing = DBG && wg == 0 && tid == 0;
@@ -434,6 +434,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     eps_to_lds();
     if constexpr (MISS) __syncthreads();
     uint32_t C = 0, Sx = 0, seq = 0, nev = 0;
+    uint32_t pcur = 0; // index into p.pred of the first predicted position at or behind the cursor
+    const rs_cu32* const pred4 = (const rs_cu32*)p.pred; // (constant address space: uniform indices make scalar loads)
     uint32_t kind = RS_ADVANCE, ncons = 0;
     bool last = M == 0;
     double dbeta = 0.0;
@@ -478,26 +480,20 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         cols_landed(); // issued at the end of the last round: nothing to wait for (and no Gram atomic in flight yet)
 
         if (upd) {
-            // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave ----
             const uint32_t slotq = q & bmask;
             uint32_t xq[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) xq[t] = ring[slotq * 64u * T + (uint32_t)lane * T + t];
             const double2 mq = meta[slotq];
-            if (tid < 16) {
+            if (tid < 16) { // the update's pair table (read behind the Gram terms, below)
                 const double av = mq.x, sd = mq.y, db = dbeta;
                 const double v0 = -(av * sd * db), v1 = db * (1.0 - av) * sd, v2 = db * (2.0 - av) * sd;
                 // (window codes: the x form 00 / 01 / 11 = genotype 0 / 1 / 2; 10 = missing call, addend 0)
                 auto addend = [&](uint32_t c) { return 0.0 + ((c == 0u) ? v0 : ((c == 1u) ? v1 : ((c == 3u) ? v2 : 0.0))); };
                 tab[tid] = make_double2(addend((uint32_t)tid & 3u), addend(((uint32_t)tid >> 2) & 3u));
             }
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
-            lap(1);
-            if (timing) p.trace[5 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
 
-            // ---- integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind q (their dots were taken before this
+            // ---- FIRST what the walker waits for (they need the window's codes only, not eps): the integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind q (their dots were taken before this
             // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
             const uint32_t V = Sx - (q + 1u);
             const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
@@ -588,9 +584,16 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
             }
             if (with_gram) ++nev;
-            eps_to_lds(); // (build MISS: behind the Gram terms, which are what the walker waits for; read by the refill below, behind a barrier)
             lap(2);
             if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+            // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave, while the
+            // Gram atomics are on their way (an LDS-only barrier: __syncthreads() would wait for them to be performed) ----
+            rs_lds_barrier();
+#pragma unroll
+            for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
+            eps_to_lds(); // (build MISS: read by the refill below, behind a barrier)
+            lap(1);
+            if (timing) p.trace[5 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
@@ -681,7 +684,6 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 const uint32_t kl = nk + (((uint32_t)lane - nk) & (uint32_t)(RS_PF - 1));
                 if (lane < RS_PF && kl - nk < m) {
                     meta[pos_of(kl) & bmask] = rs_lane_meta();
-                    if constexpr (!MISS) pflag[pos_of(kl) & bmask] = (uint8_t)(rs_lane_bold() != 0.0 ? 1 : 0); // (build MISS: no pivots; the LDS copy of eps lives there)
                     lane_load(pos_of(kl + (uint32_t)RS_PF), pos_of(kl + 2u * (uint32_t)RS_PF));
                 }
             }
@@ -695,48 +697,67 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         lap(4);
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
         // ---- Gram terms with the batch's pivots.  A marker whose effect is non-zero at sweep start WILL change (a predicted event):
-        // the first RS_PMAX of them in the window as it stands now, [Cn, Sn), are this batch's pivots, and every column of the batch
-        // behind one of them takes its integer Gram term with it here, where both columns are in LDS -- the walker then needs no
-        // round trip when that pivot's turn comes (message RS_PIVOT).  Wave 0 finds the pivots, in position order.
-        if (p.pivots) { // (uniform; without the option the round goes straight from the refill's barrier to the finishing threads)
-        if (tid < WAVE) {
+        // the first RS_PMAX of them in the window as it stands now, [Cn, Sn), are this batch's pivots -- read off the sorted list of
+        // predicted positions, p.pred, by scalar loads: every wave (and the walker) finds the same ones without a word exchanged --
+        // and every column of the batch behind one of them takes its integer Gram term with it here, where both columns are in LDS:
+        // the walker then needs no round trip when that pivot's turn comes (message RS_PIVOT).  Each wave takes the terms of the
+        // columns it streamed: two pivots to a pass, their lane sums packed into one word per column (a lane adds at most 64 T), up
+        // to sixteen columns to one reduce-scatter; lane c then holds column c's two wave sums and sends them as ONE 8-byte atomic add
+        // (two 32-bit fields: the walker decodes differences).  Nothing goes through LDS and nobody waits for anybody.
+        if constexpr (!MISS) {
+        if (p.pivots) { // (uniform)
+            // pcur: index of the first predicted position >= the cursor.  A message consumes at most one of them: its event.
+            const uint32_t pe0 = pred4[pcur], pe1 = pred4[pcur + 1u], pe2 = pred4[pcur + 2u], pe3 = pred4[pcur + 3u], pe4 = pred4[pcur + 4u];
+            const bool hit = upd && pe0 == q;
+            if (hit) ++pcur;
+            const uint32_t pv[RS_PMAX] = {hit ? pe1 : pe0, hit ? pe2 : pe1, hit ? pe3 : pe2, hit ? pe4 : pe3};
             uint32_t np = 0;
-            for (uint32_t b0 = Cn; b0 < Sn && np < (uint32_t)RS_PMAX; b0 += WAVE) {
-                const uint32_t pp = b0 + (uint32_t)lane;
-                unsigned long long m = __ballot(pp < Sn && pflag[pp & bmask] != 0);
-                while (m && np < (uint32_t)RS_PMAX) {
-                    const uint32_t b = (uint32_t)(__ffsll((long long)m) - 1);
-                    if (lane == 0) pivl[1 + np] = b0 + b;
-                    ++np;
-                    m &= m - 1ull;
-                }
-            }
-            if (lane == 0) pivl[0] = np;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {
-            const uint32_t np = pivl[0];
-            for (uint32_t ip = 0; ip < np; ++ip) { // wave-uniform loops
-                const uint32_t pv = pivl[1 + ip];
-                GramPivot gq[T];
+#pragma unroll
+            for (int ip = 0; ip < RS_PMAX; ++ip) np += pv[ip] < Sn ? 1u : 0u; // (ascending: the ones inside the window come first)
+            const uint32_t ncol = nk - round_k0; // columns this wave streamed this round
+            for (uint32_t h2 = 0; h2 < np && ncol; h2 += 2u) { // wave-uniform loops
+                const uint32_t pvA = pv[h2 ? 2 : 0], pvB = (h2 + 1u < np) ? pv[h2 ? 3 : 1] : 0xffffffffu;
+                GramPivot gA[T], gB[T];
                 {
-                    const uint32_t* rp = ring + (pv & bmask) * 64u * T + (uint32_t)lane * T;
+                    const uint32_t* ra = ring + (pvA & bmask) * 64u * T + (uint32_t)lane * T;
+                    const uint32_t* rb = ring + ((pvB != 0xffffffffu ? pvB : pvA) & bmask) * 64u * T + (uint32_t)lane * T;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) gq[t] = gram_pivot_x(rp[t]);
+                    for (int t = 0; t < T; ++t) {
+                        gA[t] = gram_pivot_x(ra[t]);
+                        gB[t] = gram_pivot_x(rb[t]);
+                    }
                 }
-                for (uint32_t k = round_k0; k < nk; ++k) {
-                    const uint32_t pos = pos_of(k);
-                    if (pos <= pv) continue;
-                    const uint32_t* rp = ring + (pos & bmask) * 64u * T + (uint32_t)lane * T;
-                    uint32_t g = 0u;
+                for (uint32_t c0 = 0; c0 < ncol; c0 += 16u) {
+                    uint32_t acc[16];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) g += gram16x(rp[t], gq[t]);
-                    const uint32_t tot = wave_sum_u32(g);
-                    if (lane == 0) pterm[(pos - Sx) * (uint32_t)RS_PMAX + ip] = tot;
+                    for (int k = 0; k < 16; ++k) {
+                        acc[k] = 0u;
+                        if (c0 + (uint32_t)k < ncol) { // wave-uniform
+                            const uint32_t pos = pos_of(round_k0 + c0 + (uint32_t)k);
+                            if (pvA < pos) {
+                                const uint32_t* rp = ring + (pos & bmask) * 64u * T + (uint32_t)lane * T;
+                                uint32_t w[T], ga = 0u, gb = 0u;
+#pragma unroll
+                                for (int t = 0; t < T; ++t) w[t] = rp[t];
+#pragma unroll
+                                for (int t = 0; t < T; ++t) ga += gram16x(w[t], gA[t]);
+                                if (pvB < pos) {
+#pragma unroll
+                                    for (int t = 0; t < T; ++t) gb += gram16x(w[t], gB[t]);
+                                }
+                                acc[k] = ga | (gb << 16);
+                            }
+                        }
+                    }
+                    const uint32_t tot = wave_sum16_rows(acc, lane); // every lane: the wave's sums of accumulator lane & 15
+                    if ((uint32_t)lane < 16u && c0 + (uint32_t)lane < ncol && tot) {
+                        const uint32_t pos = pos_of(round_k0 + c0 + (uint32_t)lane);
+                        const unsigned long long w = (unsigned long long)(tot & 0xffffu) | ((unsigned long long)(tot >> 16) << 32);
+                        __hip_atomic_fetch_add(p.pacc + ((size_t)(wg % p.rsh) * RS_RB + (pos % RS_RB)) * 2u + (h2 >> 1), w, HG_RLX_AGENT);
+                    }
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         // One thread per refilled position adds the eight group sums of its column in order and sends the workgroup's part of s1 as
         // a 51-bit fixed-point integer -- taken from "x + 1.5 2^52" (round to nearest, exact for |x| < 2^51) -- by an 8-byte atomic add
@@ -762,19 +783,6 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
-            const uint32_t np = p.pivots ? pivl[0] : 0u;
-            if (np) {
-                unsigned long long w01 = 0ull, w23 = 0ull;
-                for (uint32_t ip = 0; ip < np; ++ip)
-                    if (pivl[1 + ip] < Sx + t) {
-                        const unsigned long long v = (unsigned long long)pterm[t * (uint32_t)RS_PMAX + ip] << (32u * (ip & 1u));
-                        if (ip < 2u) w01 += v;
-                        else w23 += v;
-                    }
-                unsigned long long* pw = p.pacc + ((size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB)) * 2u;
-                if (w01) __hip_atomic_fetch_add(pw, w01, HG_RLX_AGENT);
-                if (w23) __hip_atomic_fetch_add(pw + 1, w23, HG_RLX_AGENT);
-            }
         }
         wait_vmcnt<0>();
         lap(5);
@@ -1899,11 +1907,18 @@ __global__ __launch_bounds__(256) void k_res_finish(ResParams p)
         if (lc[i]) atomicAdd(p.cass + i, lc[i]);
 }
 
+} // namespace hg
+
+#include "hg_walker2.hip.h"
+
+namespace hg {
+
 template <int T, int DBG, int MISS>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p, const ResParams* pg)
 {
     if (blockIdx.x < p.W) res_streamer<T, DBG, MISS>(p, hg_smem);
-    else res_walker<DBG, MISS>(*pg, hg_smem); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
+    else if (p.walker == 2) res_walker2<DBG, MISS>(*pg); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
+    else res_walker<DBG, MISS>(*pg, hg_smem);
 }
 
 } // namespace hg

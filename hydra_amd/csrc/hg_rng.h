@@ -93,8 +93,8 @@ HG_HD double int_float_pair(Gen& g, int& bucket)
     return r;
 }
 
-template <class Gen>
-HG_HD double unit_exponential(Gen& g, const ZigTables& t)
+template <class Gen, class Tab>
+HG_HD double unit_exponential(Gen& g, const Tab& t)
 {
     double shift = 0.0;
     for (;;) {
@@ -114,8 +114,8 @@ HG_HD double unit_exponential(Gen& g, const ZigTables& t)
     }
 }
 
-template <class Gen>
-HG_HD double unit_normal(Gen& g, const ZigTables& t)
+template <class Gen, class Tab>
+HG_HD double unit_normal(Gen& g, const Tab& t)
 {
     for (;;) {
         int i;
@@ -147,8 +147,8 @@ HG_HD double unit_normal(Gen& g, const ZigTables& t)
 }
 
 // Distributions_boost::norm_rng(mean, sigma2), with sigma = sqrt(sigma2) given
-template <class Gen>
-HG_HD double norm_rng_sd(Gen& g, const ZigTables& t, double mean, double sigma)
+template <class Gen, class Tab>
+HG_HD double norm_rng_sd(Gen& g, const Tab& t, double mean, double sigma)
 {
     return unit_normal(g, t) * sigma + mean;
 }

@@ -107,6 +107,8 @@ struct hgibbs_ctx {
     uint8_t* adaV = nullptr;
     double *s_mave = nullptr, *s_mstd = nullptr, *s_bold = nullptr;
     int32_t* s_ga = nullptr;
+    uint32_t* pred = nullptr;     // resident engine: the sweep positions whose marker has a non-zero effect at sweep start, ascending, then 16 sentinels
+    uint32_t* pred_cnt = nullptr; // per 4096 positions: how many of them (k_pred_*)
     unsigned long long* dbg = nullptr; // 8 words, device
     bool debug_timing = false;
     bool w_kernel_timing = false; // BayesW: HIP events around every k_bw_sums launch (bench.py's roofline leg)
@@ -151,6 +153,7 @@ struct hgibbs_ctx {
     bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
+    int res_walker = 0;       // option walker: 0 auto, 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
     ResMsg* res_msg = nullptr;
@@ -361,6 +364,69 @@ __global__ void k_gather_meta(const int32_t* __restrict__ order, const double* _
     s_mstd[j] = mstd[m];
     s_bold[j] = beta[m];
     s_ga[j] = groups[m] | (adaV[m] ? 0x40000000 : 0) | (counts[3ull * m + 2] ? 0x20000000 : 0);
+}
+
+// The sweep positions whose marker's effect is non-zero at sweep start (it WILL change: a predicted event), ascending, followed by 16
+// sentinels 0xffffffff: the resident engine's streaming workgroups and its walker both read the window's pivots off this list.
+// Three small launches: per chunk of 4096 positions a count, one workgroup's exclusive scan of the counts, an order-preserving scatter.
+constexpr uint32_t PRED_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_pred_count(const double* __restrict__ s_bold, uint32_t M, uint32_t* cnt)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * PRED_CHUNK;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < PRED_CHUNK / 256; ++i) {
+        const uint32_t j = base + i * 256 + threadIdx.x;
+        n += (uint32_t)__popcll(__ballot(j < M && s_bold[j] != 0.0));
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n; // (every lane of a wave holds the wave's count)
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(1024) void k_pred_scan(uint32_t* cnt, uint32_t nchunk)
+{
+    __shared__ uint32_t tot[1024];
+    const uint32_t per = (nchunk + 1023u) / 1024u, lo = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < lo + per && i < nchunk; ++i) s += cnt[i];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const uint32_t v = tot[t];
+            tot[t] = run;
+            run += v;
+        }
+        cnt[nchunk] = run; // the list's length
+    }
+    __syncthreads();
+    uint32_t run = tot[threadIdx.x];
+    for (uint32_t i = lo; i < lo + per && i < nchunk; ++i) {
+        const uint32_t v = cnt[i];
+        cnt[i] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void k_pred_scatter(const double* __restrict__ s_bold, uint32_t M, const uint32_t* __restrict__ cnt, uint32_t nchunk, uint32_t* pred)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * PRED_CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = cnt[blockIdx.x];
+    for (uint32_t i = 0; i < PRED_CHUNK / 256; ++i) {
+        const uint32_t j = base + i * 256 + threadIdx.x;
+        const bool f = j < M && s_bold[j] != 0.0;
+        const unsigned long long m = __ballot(f);
+        __syncthreads(); // (the previous pass's wsum has been read)
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (f) pred[run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16) pred[cnt[nchunk] + threadIdx.x] = 0xffffffffu;
 }
 
 __global__ void k_set_eps(double* eps, const double* __restrict__ src, uint32_t n_local, uint32_t n_pad)
@@ -605,7 +671,7 @@ int hgibbs_destroy(hgibbs_t h)
         if (h->peer_base[r] && h->peer_base[r] != h->mbox) (void)hipIpcCloseMemHandle(h->peer_base[r]);
     if (h->mbox) (void)hipFree(h->mbox);
     void* ptrs[] = {h->bed, h->eps[0], h->eps[1], h->mave, h->mstd, h->counts, h->groups, h->beta, h->comp, h->acum, h->order,
-                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket, h->res_acc, h->res_msg, h->res_state, h->res_trace};
+                    h->adaV, h->covX, h->s_mave, h->s_mstd, h->s_bold, h->s_ga, h->pred, h->pred_cnt, h->dbg, h->cass, h->tables, h->mt, h->zig, h->desc, h->partials, h->totals, h->ticket, h->sums, h->scratch, h->carry, h->ahead_raw, h->apartials, h->aticket, h->res_acc, h->res_msg, h->res_state, h->res_trace};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->desc_host) (void)hipHostFree(h->desc_host);
@@ -732,6 +798,8 @@ static int alloc_problem(hgibbs_ctx* h, uint32_t n_global, uint32_t n_local, uin
     HIP_TRY(hipMalloc(&h->s_mstd, (size_t)M * sizeof(double)));
     HIP_TRY(hipMalloc(&h->s_bold, (size_t)M * sizeof(double)));
     HIP_TRY(hipMalloc(&h->s_ga, (size_t)M * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->pred, ((size_t)M + 16) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->pred_cnt, ((size_t)(M + PRED_CHUNK - 1) / PRED_CHUNK + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&h->groups, (size_t)M * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(h->beta, 0, (size_t)M * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->comp, 0, (size_t)M * sizeof(int32_t), h->stream));
@@ -1154,6 +1222,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         h->window = (uint32_t)value;
     } else if (!std::strcmp(name, "pivots")) {
         h->res_pivots = value != 0;
+    } else if (!std::strcmp(name, "walker")) {
+        if (value < 0 || value > 2) return fail("walker must be 0 (auto), 1 (first) or 2 (second)");
+        h->res_walker = (int)value;
     } else if (!std::strcmp(name, "res_cus")) {
         if (value < 0 || value > 4096) return fail("res_cus must be in [0,4096]");
         h->res_cus = (uint32_t)value;
@@ -1328,6 +1399,21 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
     p.all_ada = h->res_all_ada ? 1 : 0;
+    {
+        // the second walker: every marker takes a uniform, the mixture tables and the tabulated bound fit its LDS, one rank
+        const bool w2_ok = h->res_all_ada && p.GK <= HT_LDS && G <= RS_FG && p.nranks == 1;
+        if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks)", RS_FG, HT_LDS);
+        p.walker = (h->res_walker == 2) ? 2 : 1; // (auto: the first walker -- the second is not faster yet)
+    }
+    p.pred = h->pred;
+    {
+        // the predicted events of this sweep, in sweep order (read by the streaming workgroups and by the walker)
+        const uint32_t nchunk = (h->M + PRED_CHUNK - 1) / PRED_CHUNK;
+        k_pred_count<<<nchunk, 256, 0, h->stream>>>(h->s_bold, h->M, h->pred_cnt);
+        k_pred_scan<<<1, 1024, 0, h->stream>>>(h->pred_cnt, nchunk);
+        k_pred_scatter<<<nchunk, 256, 0, h->stream>>>(h->s_bold, h->M, h->pred_cnt, nchunk, h->pred);
+        HIP_TRY(hipGetLastError());
+    }
     p.sweep_id = ++h->res_sweep_id; // every rank runs the same sweeps on the resident engine (agreed in hgibbs_sweep): the counters stay equal
     p.trace = h->res_trace;
     p.progress = h->res_progress;
@@ -1336,7 +1422,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
-    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), rs_walker_lds(pl.B));
+    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), p.walker == 2 ? rs_walker2_lds(pl.B) : rs_walker_lds(pl.B));
     void (*kern)(ResParams, const ResParams*) = nullptr;
     const bool dbg = h->debug_timing;
     const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
@@ -1412,6 +1498,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.streamed_columns = h->M;
     s.tiles_per_workgroup_min = s.tiles_per_workgroup_max = (uint32_t)pl.T;
     s.engine = 2;
+    s.walker = (uint32_t)p.walker;
     s.rounds = st.rounds;
     s.events = st.events;
     s.advances = st.advances;

@@ -183,7 +183,7 @@ typedef struct {
     uint32_t tiles_per_workgroup_min; /* tile groups of 4096 individuals one workgroup of the sweep kernel streamed per launch: */
     uint32_t tiles_per_workgroup_max; /* > 1 means the loop's next-tile prefetch and cross-tile accumulation ran */
     uint32_t engine;          /* 1 = batch engine (one launch per event batch), 2 = resident engine (one launch per sweep) */
-    uint32_t reserved_;
+    uint32_t walker;          /* resident engine: 1 = the first walker (the workgroup in lockstep), 2 = the second (one wave walks the chain, hg_walker2.hip.h) */
     double eps_sum_drift;     /* |sum(eps) at sweep end - sum(eps) at sweep start|: s2 of a column without missing calls is taken
                                * once per sweep (src/BayesRRm.cpp:331 re-sums per marker); this is what that assumption costs */
     /* resident engine: rounds of the walker (= working_launches), events (messages that carried an update), rounds that only

@@ -27,7 +27,7 @@ def make_case(M, N, seed=7, causal_frac=0.05, missing_rate=0.0, missing_cols=1.0
     return synth.pack_bed_columns(geno), y
 
 
-def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None, missing_rate=0.0, missing_cols=1.0):
+def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None, missing_rate=0.0, missing_cols=1.0, expect_walker=None):
     bed, y = make_case(M, N, seed=M + N, causal_frac=causal_frac, missing_rate=missing_rate, missing_cols=missing_cols)
     ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
     dev = capi.Device(0)
@@ -43,6 +43,8 @@ def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1
         st = ch.state()
         ss = dev.sweep_stats()
         assert ss["engine"] == 2 and ss["launches"] == 1 and ss["accepted_markers"] == M
+        if expect_walker:
+            assert ss["walker"] == expect_walker
         if expect_T:
             assert ss["tiles_per_workgroup_max"] == expect_T
         assert np.array_equal(ch.order(), ref.arr("order")), "marker order diverged at it %d" % it
@@ -61,9 +63,10 @@ def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1
     return ch, ref, dev
 
 
+@pytest.mark.parametrize("walker", [1, 2])
 @pytest.mark.parametrize("N", [37, 1024, 4099, 9001])
-def test_small_shapes(oracle, N):
-    run_vs_oracle(oracle, 300, N)
+def test_small_shapes(oracle, N, walker):
+    run_vs_oracle(oracle, 300, N, opts={"walker": walker}, expect_walker=walker)
 
 
 @pytest.mark.parametrize("window", [8, 32, 128, 256])
