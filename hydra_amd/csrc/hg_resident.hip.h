@@ -123,6 +123,7 @@ struct ResParams {
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
+    int tune;   // experiments (option res_tune): bits 0-1: priority of the younger wave of each SIMD (waves 4 .. 7) in the refill
     int walker; // 2: the second walker (hg_walker2.hip.h: one wave walks the chain, the others serve it), else the first
     const uint32_t* pred; // the sweep positions whose marker has a non-zero effect at sweep start (predicted events), ascending, then 16 sentinels 0xffffffff
     int all_ada; // 1: no marker is frozen out (adaV all ones, the usual case): a marker's uniform is its distance from the cursor
@@ -546,7 +547,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         const double mine = ((double)(apt & 0xffffu) + mqv * (double)(apt >> 16)) + (mj * (double)(qxt & 0xffffu) + (mj * mqv) * (double)(qxt >> 16));
                         const double MAGIC = 6755399441055744.0;
                         const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
-                        __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + mycol, RS_ONE64 | fx, HG_RLX_AGENT);
+                        __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + mycol) & bmask), RS_ONE64 | fx, HG_RLX_AGENT);
                     }
                 }
             }
@@ -580,8 +581,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 }
             }
             const uint32_t mine = wave_sum16_scatter(acc, lane); // lane c: the wave's Gram term of its column c
-            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words: count in the top byte
-                __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + i0 + (uint32_t)lane, RS_ONE | mine, HG_RLX_AGENT);
+            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words (by window slot of the column, up to the wrap): count in the top byte
+                __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + i0 + (uint32_t)lane) & bmask), RS_ONE | mine, HG_RLX_AGENT);
             }
             if (with_gram) ++nev;
             lap(2);
@@ -599,6 +600,11 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
         if constexpr (MISS) {
             if (upd) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // every wave's share of the updated LDS copy is in place
+        }
+        if ((p.tune & 3) && wave >= 4) { // (wave-uniform; the priority is an immediate)
+            if ((p.tune & 3) == 1) __builtin_amdgcn_s_setprio(1);
+            else if ((p.tune & 3) == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
         }
         const uint32_t round_k0 = nk; // this wave's columns of the round: k in [round_k0, nk) behind the passes
         uint32_t done_k0 = nk, done_m = 0; // the sets the last pass consumed: reloaded behind the raw dots
@@ -693,6 +699,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             count_w -= m;
         }
         lap(3);
+        if (p.tune & 3) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the window's new columns and this round's group sums are in LDS for every wave
         lap(4);
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
@@ -1283,7 +1290,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             // workgroups' four-term sums; the terms that do not depend on the individuals come from the markers' counts
             const int ws = tid >> 6;
             const uint32_t par = (nev - 1u) & 1u;
-            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < gV) {
+            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < B) {
                 const unsigned long long* row = p.gacc64 + ((size_t)par * RS_NSH + (uint32_t)ws) * RS_GROW + 4u * (uint32_t)lane;
                 const unsigned long long want = cntG[0 + ((uint32_t)ws < p.W % p.nsh ? 0 : 1)];
                 const unsigned long long t0 = wall_clock64();
@@ -1298,7 +1305,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         d[i] = v[i] - gprev64[par][i];
-                        ok = ok && (4u * (uint32_t)lane + (uint32_t)i >= gV || (d[i] >> 56) == want);
+                        ok = ok && (((4u * (uint32_t)lane + (uint32_t)i - (gq + 1u)) & bmask) >= gV || (d[i] >> 56) == want); // (words are by window slot)
                     }
                     if (ok) break;
                     if (wall_clock64() - t0 > p.timeout) {
@@ -1316,7 +1323,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             __syncthreads();
             if ((uint32_t)tid < gV) {
                 unsigned long long A = 0ull;
-                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart64[sidx * RS_BMAX + (uint32_t)tid];
+                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart64[sidx * RS_BMAX + ((gq + 1u + (uint32_t)tid) & bmask)];
                 if (p.nranks > 1) {
                     // several ranks: the 56-bit sums cross as two words each, tag << 32 | half (tag = 1 | sweep | event: self-validating)
                     const unsigned long long tag = (0x80000000ull | ((p.sweep_id & 0x7full) << 24) | (unsigned long long)(nev & 0xffffffu)) << 32;
@@ -1364,7 +1371,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         } else if (pendG && gV) {
             const int ws = tid >> 6;
             const uint32_t par = (nev - 1u) & 1u;
-            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < gV) {
+            if ((uint32_t)ws < p.nsh && 4u * (uint32_t)lane < B) {
                 const uint32_t* row = p.gacc + ((size_t)par * RS_NSH + (uint32_t)ws) * RS_GROW + 4u * (uint32_t)lane;
                 const uint32_t want = cntG[0 + ((uint32_t)ws < p.W % p.nsh ? 0 : 1)];
                 const unsigned long long t0 = wall_clock64();
@@ -1374,9 +1381,10 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
                 for (;;) {
                     v = rs_load16(row);
                     d = par ? (v - gprev1) : (v - gprev0);
-                    const uint32_t i = 4u * (uint32_t)lane;
-                    const bool ok = (d.x >> 24) == want && (i + 1u >= gV || (d.y >> 24) == want) && (i + 2u >= gV || (d.z >> 24) == want) &&
-                                    (i + 3u >= gV || (d.w >> 24) == want);
+                    // (words are by window slot: one is in use iff its slot's column lies behind the event)
+                    const uint32_t i = 4u * (uint32_t)lane - (gq + 1u);
+                    const bool ok = ((i & bmask) >= gV || (d.x >> 24) == want) && (((i + 1u) & bmask) >= gV || (d.y >> 24) == want) &&
+                                    (((i + 2u) & bmask) >= gV || (d.z >> 24) == want) && (((i + 3u) & bmask) >= gV || (d.w >> 24) == want);
                     if (ok) break;
                     if (wall_clock64() - t0 > p.timeout) {
                         sh.fl[WF_ABORT] = 1u;
@@ -1396,7 +1404,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             __syncthreads();
             uint32_t A = 0u;
             if ((uint32_t)tid < gV)
-                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart[sidx * RS_BMAX + (uint32_t)tid];
+                for (uint32_t sidx = 0; sidx < p.nsh; ++sidx) A += sh.gpart[sidx * RS_BMAX + ((gq + 1u + (uint32_t)tid) & bmask)];
             if (p.nranks > 1) {
                 // this rank's sums go to every peer's mailbox, the peers' arrive in mine (integers: the total does not depend on the
                 // order).  A word says itself what it is -- sweep << 48 | event << 24 | sum, one 8-byte store -- so there is no flag

@@ -6,18 +6,20 @@
 // round trip through the streaming workgroups (a predicted pivot: its Gram terms came with the columns), that serial work IS the
 // round.  Here the roles are split over the workgroup's eight waves and nothing on the chain ever waits for global memory:
 //
-//   wave 0      the CHAIN: per window position (four to a lane, in registers) the dot as streamed, its Gram corrections, mave, mstd
-//               and the old effect; per round [absorb dots that arrived | bound test of the positions behind the cursor, no
-//               exponential (the tabulated convex bound) | first candidate by ballots | the reference's exact decision and draw
-//               (a5-a7, src/BayesRRm.cpp:1744-1753,1859-1921) | message | corrections of the positions behind the event].  It reads and
-//               writes LDS only, and posts the 16-byte message; no barrier, no vmcnt wait.
-//   wave 1      the FOLDER: polls the batch counters, turns the fixed-point sums of completed refill batches into dots (and the
+//   waves 0-3   the CHAIN: one window position per lane (wave w holds the window slots 64 w .. 64 w + 63), in registers the dot as
+//               streamed, its Gram corrections, mave, mstd and the old effect.  A wave issues one instruction every five clocks or
+//               so: what is parallel over the window -- absorbing dots that arrived, the Gram corrections behind an event, the
+//               bound test without an exponential (the tabulated convex bound) -- runs on four waves on four SIMDs, one position per
+//               lane; what is serial -- the first candidate, the reference's exact decision and draw (a5-a7,
+//               src/BayesRRm.cpp:1744-1753,1859-1921), the message -- on wave 0, the DECIDER.  It tells the others what happened by a
+//               RECORD in LDS (event, correction terms, how the window moves, how far dots may be absorbed), they answer with the
+//               candidate masks of their slots.  When an event needs the round trip through the streaming workgroups, every chain
+//               lane polls the Gram accumulators' words of ITS slot (they are indexed by window slot) in all shard rows itself.
+//   wave 4      the FOLDER: polls the batch counters, turns the fixed-point sums of completed refill batches into dots (and the
 //               columns' Gram terms with their batch's pivots) and publishes "every position below F has its dot".
-//   wave 2      the HOUSEKEEPER: generator blocks and their thresholds ahead of the chain (a ring of four), marker metadata two
+//   wave 5      the HOUSEKEEPER: generator blocks and their thresholds ahead of the chain (a ring of four), marker metadata two
 //               windows ahead, the list of predicted positions, and the results of consumed positions (numerator into Acum's slot,
 //               new effect and component of an event) out to global memory.
-//   waves 4-7   the COLLECTORS: when the chain posts an event that needs the round trip, they poll the Gram accumulators' shard
-//               rows (two each) until every word carries its full arrival count and leave the sums in LDS.
 //
 // The waves hand over through LDS words (a writer finishes its data, waits lgkmcnt(0), then publishes a counter; LDS serves a
 // wave's operations in order).  Every wait is bounded by ResParams::timeout and ends the sweep with error 3.
@@ -33,29 +35,50 @@ constexpr uint32_t W2_RR = 1024;             // results ring (positions)
 constexpr uint32_t W2_EV = 64;               // event records in flight to the housekeeper
 constexpr uint32_t W2_PRED = 1024;           // predicted positions staged
 constexpr uint32_t W2_NB = 256;              // refill batches on record (a batch on record has at least one position in the window)
-constexpr int W2_NCOL = 4;                   // collector waves (4 .. 7)
+constexpr int W2_NCH = 4;                    // chain waves (0 .. 3); the folder is wave 4, the housekeeper wave 5
+constexpr uint32_t W2_NREC = 8;              // records in the ring (the decider waits for every answer before the next one: two would do)
 
 enum {
-    S_FPUB = 0, // folder -> chain: every position below has its dot
+    S_FPUB = 0, // folder -> decider: every position below has its dot
     S_MPUB,     // housekeeper -> chain: positions below have their metadata staged
-    S_CPUB,     // chain -> housekeeper: cursor (positions below are consumed, their numerators are in the results ring)
-    S_SXPUB,    // chain -> folder: positions below have been announced to the streaming workgroups (batch[] is set)
-    S_GREQ,     // chain -> collectors: number of the event whose Gram terms are wanted
-    S_GV,       //   ... columns behind it
-    S_GDONE,    // [W2_NCOL] collectors -> chain: number of the event whose sums are in gpart
-    S_BLK = S_GDONE + W2_NCOL, // housekeeper -> chain: generator blocks made
-    S_GPOS,     // chain -> housekeeper: generator words consumed (absolute, from the start of the block the sweep began in)
-    S_PLD,      // housekeeper -> chain: predicted positions staged (index)
-    S_PCUR,     // chain -> housekeeper: index of the first predicted position at or behind the cursor
-    S_RDONE,    // folder -> chain: refill batches every streaming workgroup has completed
-    S_EVN,      // chain -> housekeeper: events recorded
+    S_CPUB,     // decider -> housekeeper: cursor (positions below are consumed, their numerators are in the results ring)
+    S_SEQPUB,   // decider -> folder: messages posted (the batches on record, bl_*)
+    S_RECSEQ,   // decider -> chain: records published
+    S_BLK,      // housekeeper -> decider: generator blocks made
+    S_GPOS,     // decider -> housekeeper: generator words consumed (absolute, from the start of the block the sweep began in)
+    S_PLD,      // housekeeper -> decider: predicted positions staged (index)
+    S_PCUR,     // decider -> housekeeper: index of the first predicted position at or behind the cursor
+    S_RDONE,    // folder -> decider: refill batches every streaming workgroup has completed
+    S_EVN,      // decider -> housekeeper: events recorded
     S_ABORT,
     S_END,
     S_ERR,
-    S_WPUB,     // housekeeper -> chain: results of the positions below are written (their ring entries and metadata slots are free)
-    S_EVW,      // housekeeper -> chain: event records taken
+    S_WPUB,     // housekeeper -> decider: results of the positions below are written (their ring entries and metadata slots are free)
+    S_EVW,      // housekeeper -> decider: event records taken
     S_NWORDS = 32
 };
+// a record: what the decider tells the chain waves (words of 4 bytes)
+enum {
+    R_TYPE = 0, // RT_*
+    R_Q,        // position of the event
+    R_CN,       // the cursor behind it
+    R_SXO,      // the window's end before
+    R_SXN,      //   ... and after: the slots of the consumed positions take the positions [R_SXO, R_SXN)
+    R_FD,       // dots may be absorbed, and positions tested, below this position
+    R_SEQ,      // the message's number = the refill batch of the new positions
+    R_PIN,      // index of that batch's first pivot in the list of predicted positions
+    R_PIQ,      // RT_PIVOT: the event's index in that list
+    R_NEV,      // RT_EVENT: its number among the events that take the round trip (parity of the Gram accumulators)
+    R_GPOSR,    // the generator's ring index at the new cursor
+    R_PFN,      // fired pivots on record (pf_*)
+    R_DB = 12,  // (two words each) dbeta, then the event's mave, mstd, and (build MISS) its genotype sum and missing calls
+    R_MQ = 14,
+    R_SQ = 16,
+    R_GSQ = 18,
+    R_NMQ = 20,
+    R_WORDS = 32
+};
+enum { RT_EXTEND = 0, RT_ADVANCE = 1, RT_PIVOT = 2, RT_EVENT = 3, RT_END = 4 };
 
 // LDS of the walker workgroup.  The carve-up is a list of byte offsets (host and device agree on its end); the device takes its
 // pointers from it with the LDS address space in their TYPE: res_walker2 is a function of its own (not inlined into the kernel), and
@@ -81,7 +104,7 @@ enum {
     X(unsigned long long, rprev2, (size_t)RS_RB)                                                                                              \
     X(unsigned long long, pprev, (size_t)2 * RS_RB)                                                                                           \
     X(double, pf_val, (size_t)RS_PFIRE * 3) /* fired pivots: (dbeta, mave, mstd) */                                                           \
-    X(unsigned long long, gpart64, (size_t)W2_NCOL * RS_BMAX) /* the collectors' sums (the plain build uses the first half as 4-byte words) */ \
+    X(uint32_t, ans, (size_t)W2_NCH * 4)  /* the chain waves' answers: {candidate mask (two words), records answered, -}, 16 bytes each */        \
     X(uint32_t, mt, (size_t)W2_RING)      /* untempered generator words */                                                                    \
     X(int32_t, marker, MR)                                                                                                                    \
     X(int32_t, ga, MR)                                                                                                                        \
@@ -93,6 +116,8 @@ enum {
     X(uint32_t, bl_pi, (size_t)W2_NB)     /* per batch: index of its first pivot in the list of predicted positions */                        \
     X(uint32_t, bl_p0, (size_t)W2_NB)     /*   that pivot's position (0xffffffff: none) */                                                    \
     X(uint32_t, bl_np, (size_t)W2_NB)     /*   its number of pivots */                                                                        \
+    X(uint32_t, bl_sn, (size_t)W2_NB)     /*   the window's end behind its message: the batch's positions end there */                        \
+    X(uint32_t, rec, (size_t)W2_NREC * R_WORDS) /* the decider's records */                                                                   \
     X(uint32_t, pf_pos, RS_PFIRE)         /* pivots fired while columns streamed before their update were without their dot */                \
     X(uint32_t, pf_msg, RS_PFIRE)                                                                                                             \
     X(uint32_t, pf_pi, RS_PFIRE)                                                                                                              \
@@ -203,7 +228,6 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     const double* const zig_ex = pr.zig.ex; \
     const double* const zig_ey = pr.zig.ey; \
     const Walk2Lds sh = walk2_lds(B); \
-    W2_LDS uint32_t* const gpart = (W2_LDS uint32_t*)sh.gpart64; \
     const uint32_t cntG[2] = {W / nsh + (W % nsh ? 1u : 0u), W / nsh}; \
     const uint32_t cntR[2] = {W / rsh + (W % rsh ? 1u : 0u), W / rsh}; \
     const uint32_t Sx0 = (B < M) ? B : M; \
@@ -235,85 +259,51 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
 {
     W2_PROLOGUE
     // =====================================================================================================================
-    // the chain.  Everything per window position is straight-line code over the lane's four slots (reads with clamped addresses,
-    // results selected): the four dependent chains then run interleaved -- one LDS round trip per step, not one per slot and step
+    // the chain: wave w holds the window slots 64 w + lane, one position per lane; wave 0 also decides
     // =====================================================================================================================
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t NSL = B >= 64u ? B / 64u : 1u; // window slots per lane: slot = 64 i + lane
-    uint32_t C = 0, Sx = Sx0, Fs = 0, base = 0, seq = 0, nev = 0, pi = 0, evn = 0, pf_n = 0;
-    uint32_t gpos = rng_idx0, gposr = rng_idx0 % W2_RING, blk = 1u;
-    // per slot: the dot as streamed, its Gram corrections, the marker's (mave, mstd, old effect x (N - 1)), the tabulated bound's scale and table offset of its group, its refill batch and that batch's first pivot index
-    double dpr[4], dp[4], mave[4], mstd[4], boldn[4], fsc[4], gsm[4], nms[4];
-    uint32_t fof[4], sbt[4], spi[4];
-    bool prd[4], son[4]; // the marker's effect is non-zero at sweep start (a predicted event); the slot exists
-    uint32_t sl[4];      // the slot (clamped to an existing one)
-    uint32_t n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0, n_pred = 0; // (scalars: the control flow around them is uniform)
+    const bool decider = wave == 0;
+    const uint32_t nch = B >= 64u ? B / 64u : 1u; // chain waves in use
+    const uint32_t slot = (uint32_t)wave * 64u + (uint32_t)lane;
+    const bool son = slot < B;
+    const uint32_t sl = son ? slot : 0u;
+    // the slot's position: the dot as streamed, its Gram corrections, the marker's (mave, mstd, old effect x (N - 1)), the tabulated
+    // bound's scale and table offset of its group, its refill batch and that batch's first pivot index
+    double dpr = 0.0, dp = 0.0, mave = 0.0, mstd = 0.0, boldn = 0.0, fsc = 0.0, gsm = 0.0, nms = 0.0;
+    uint32_t fof = 0, sbt = 0, spi = 0;
+    bool prd = false; // the marker's effect is non-zero at sweep start (a predicted event)
+    uint32_t C = 0, Sx = 0, Fs = 0, base = 0, gposr = rng_idx0 % W2_RING; // (every chain wave follows them through the records)
+    // the Gram accumulators' words of this slot as last seen, per shard row and parity (they only ever grow: what an event added is
+    // the difference; no store ever touches them -- adds are performed at the memory side, and a store could overtake or be overtaken)
+    // (two arrays with static accesses only -- both values read, one selected -- so that they stay in registers)
+    uint32_t gpa32[RS_NSH], gpb32[RS_NSH];
+    unsigned long long gpa64[RS_NSH], gpb64[RS_NSH];
+#pragma unroll
+    for (int r = 0; r < RS_NSH; ++r) {
+        gpa32[r] = gpb32[r] = 0u;
+        gpa64[r] = gpb64[r] = 0ull;
+    }
+    const uint32_t* const gacc = pr.gacc;
+    const unsigned long long* const gacc64 = pr.gacc64;
+    uint32_t rno = 0; // records taken
+
+    // ---- the decider's own state (wave 0; uniform) ----
+    uint32_t seq = 0, nev = 0, pi = 0, evn = 0, pf_n = 0, gpos = rng_idx0, blk = 1u;
+    uint32_t rdone_seen = 0, wpub_seen = 0, evw_seen = 0, pld_seen = W2_PRED, fpub_seen = 0, mpub_seen = m0;
+    unsigned long long cm[W2_NCH] = {0ull, 0ull, 0ull, 0ull}; // candidates among the tested positions [C, Fs), by chain wave
+    uint32_t n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0, n_pred = 0;
+    uint32_t err = 0;
+    bool failed = false;
     unsigned long long tacc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned long long tmark = DBG ? wall_clock64() : 0ull;
     auto lap = [&](int i) {
-        if (DBG) {
+        if (DBG && decider) {
             const unsigned long long now = wall_clock64();
             tacc[i] += now - tmark;
             tmark = now;
         }
     };
-    uint32_t err = 0;
-    if (DBG) { // what a clock read costs (ticks per 64 reads, in t[7]): the stage clocks above include one each
-        const unsigned long long c0 = wall_clock64();
-        unsigned long long c1 = c0;
-#pragma unroll 1
-        for (int i = 0; i < 64; ++i) c1 = wall_clock64() + (c1 & 1ull);
-        tacc[7] = c1 - c0;
-        // the speed of this wave where it runs (next to the other roles' polling): 1024 dependent f64 adds (t[5]), 256 dependent LDS reads (t[6])
-        {
-            double a = (double)lane;
-            const unsigned long long d0 = wall_clock64();
-#pragma unroll 1
-            for (int i = 0; i < 128; ++i) {
-                asm volatile("v_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0\n\tv_add_f64 %0, %0, 1.0" : "+v"(a));
-            }
-            const unsigned long long d1 = wall_clock64();
-            uint32_t x = (uint32_t)lane & 3u;
-#pragma unroll 1
-            for (int i = 0; i < 256; ++i) x = sh.pf_pos[x & 15u] & 3u;
-            const unsigned long long d2 = wall_clock64();
-            tacc[7] += (unsigned long long)(x & 0u) + (unsigned long long)(a < 0.0 ? 1 : 0) + 0ull * (d2 - d0 + d1);
-        }
-        tmark = wall_clock64();
-    }
     auto pos_of_slot = [&](uint32_t s, uint32_t c) { return c + ((s - c) & bmask); };
-    // the slot's new position j (where `take`): metadata from the ring, no dot yet, no corrections yet
-    auto take_meta = [&](int i, uint32_t j, bool take, uint32_t batch_no, uint32_t batch_pi) {
-        const uint32_t ms = (take ? j : 0u) & mrmask;
-        const double a = sh.mave[ms], d = sh.mstd[ms], b = sh.bold[ms];
-        const int g = sh.ga[ms] & 0x0fffffff;
-        const double sc = sh.fscale[g];
-        mave[i] = take ? a : mave[i];
-        mstd[i] = take ? d : mstd[i];
-        boldn[i] = take ? b * n_minus_1 : boldn[i];
-        prd[i] = take ? b != 0.0 : prd[i];
-        fsc[i] = take ? sc : fsc[i];
-        fof[i] = take ? (uint32_t)g * (uint32_t)(RS_FN + 1) : fof[i];
-        dp[i] = take ? 0.0 : dp[i];
-        dpr[i] = take ? 0.0 : dpr[i];
-        sbt[i] = take ? batch_no : sbt[i];
-        spi[i] = take ? batch_pi : spi[i];
-        if constexpr (MISS) {
-            const double gs = sh.gsum[ms], nm = sh.nmis[ms];
-            gsm[i] = take ? gs : gsm[i];
-            nms[i] = take ? nm : nms[i];
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dpr[i] = dp[i] = mave[i] = mstd[i] = boldn[i] = fsc[i] = gsm[i] = nms[i] = 0.0;
-        fof[i] = sbt[i] = spi[i] = 0u;
-        prd[i] = false;
-        const uint32_t s = (uint32_t)i * 64u + (uint32_t)lane;
-        son[i] = (uint32_t)i < NSL && s < B;
-        sl[i] = son[i] ? s : 0u;
-        take_meta(i, s, son[i] && s < Sx0, 0u, 0u);
-    }
     // inside a wait: has the sweep been given up, or is it time to give it up
     auto spin_fail = [&](unsigned long long t0) {
         if (aborted()) return true;
@@ -323,8 +313,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         }
         return false;
     };
-    // wait until a counter that only grows has reached the value, with what the chain saw of it last: no LDS round trip while
-    // that is enough
+    // wait until a counter that only grows has reached the value, with what this wave saw of it last: no LDS round trip while that is enough
     auto wait_seen = [&](uint32_t& seen, int word, uint32_t value) {
         if (seen >= value) return true;
         seen = w2_ld(sh.sw + word);
@@ -337,128 +326,290 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    uint32_t rdone_seen = 0, wpub_seen = 0, evw_seen = 0, mpub_seen = m0, pld_seen = W2_PRED, fpub_seen = 0;
-    uint32_t gdone_seen[W2_NCOL] = {0u, 0u, 0u, 0u};
+    // a record goes out (decider, lane 0 writes; every field is uniform)
+    auto publish = [&](uint32_t type, uint32_t q, uint32_t Cn, uint32_t Sxo, uint32_t Sxn, uint32_t Fd, uint32_t piq, double db, double mq, double sq, double gsq, double nmq) {
+        if (lane == 0) {
+            W2_LDS uint32_t* r = sh.rec + (rno % W2_NREC) * R_WORDS;
+            r[R_TYPE] = type;
+            r[R_Q] = q;
+            r[R_CN] = Cn;
+            r[R_SXO] = Sxo;
+            r[R_SXN] = Sxn;
+            r[R_FD] = Fd;
+            r[R_SEQ] = seq;
+            r[R_PIN] = pi;
+            r[R_PIQ] = piq;
+            r[R_NEV] = nev;
+            r[R_GPOSR] = gpos % W2_RING;
+            r[R_PFN] = pf_n;
+            *(W2_LDS double*)(r + R_DB) = db;
+            *(W2_LDS double*)(r + R_MQ) = mq;
+            *(W2_LDS double*)(r + R_SQ) = sq;
+            *(W2_LDS double*)(r + R_GSQ) = gsq;
+            *(W2_LDS double*)(r + R_NMQ) = nmq;
+            w2_lds_done();
+            w2_st(sh.sw + S_RECSEQ, rno + 1u);
+        }
+    };
 
-    while (C < M) {
-        ++n_rounds;
-        if (lane == 0 && (DBG || (n_rounds & 255u) == 0u)) w2_gst(progress, ((unsigned long long)n_rounds << 8) | 1u);
-        // the generator: the words a round can reach exist
-        if (gpos + B + 96u > blk * (uint32_t)MT_N && !wait_seen(blk, S_BLK, (gpos + B + 96u + (uint32_t)MT_N - 1u) / (uint32_t)MT_N)) break;
-        // ---- the walk: up to the first event, or through the whole window ----
-        bool found = false, failed = false;
-        uint32_t qpos = 0, q_consumed = 0;
-        int q_k = 0;
-        double q_bnew = 0.0, q_bold = 0.0;
-        for (;;) {
-            // the dots that have arrived since the last look
-            lap(6);
-            fpub_seen = w2_ld(sh.sw + S_FPUB);
-            const uint32_t F = fpub_seen;
-            if (F > Fs) {
-                bool arr[4];
-                double dnew[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t j = pos_of_slot(sl[i], C);
-                    arr[i] = son[i] && j >= Fs && j < F;
-                    dnew[i] = sh.dpr[sl[i]];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dpr[i] = arr[i] ? dnew[i] : dpr[i];
-                if (pf_n) { // (uniform) the pivots that fired between a column's streaming and now: their updates were not in the streamed dot
-                    for (uint32_t f = 0; f < pf_n; ++f) {
-                        const uint32_t fmsg = w2_uni(sh.pf_msg[f]), fpos = w2_uni(sh.pf_pos[f]), fpi = w2_uni(sh.pf_pi[f]);
-                        const double fdb = w2_uni(sh.pf_val[3 * f]), fmv = w2_uni(sh.pf_val[3 * f + 1]), fsd = w2_uni(sh.pf_val[3 * f + 2]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t j = pos_of_slot(sl[i], C);
-                            const bool hit = arr[i] && fmsg > sbt[i] && fpos < j;
-                            const uint32_t ip = hit ? (fpi - spi[i]) & 3u : 0u;
-                            const double A = (double)sh.wpt[sl[i] * RS_PMAX + ip];
-                            const double xx = mstd[i] * fsd * (A - n_total * (mave[i] * fmv));
-                            dp[i] = hit ? dp[i] + fdb * xx : dp[i];
-                        }
-                    }
-                }
-                Fs = F;
-                // fired pivots stay on record only while a column streamed before their update is without its dot (entries are in message order)
-                if (pf_n) {
-                    if (Fs >= Sx) pf_n = 0;
-                    else {
-                        const uint32_t bF = w2_uni(sh.batch[Fs & bmask]);
-                        uint32_t drop = 0;
-                        while (drop < pf_n && w2_uni(sh.pf_msg[drop]) <= bF) ++drop;
-                        if (drop) {
-                            if (lane == 0)
-                                for (uint32_t f = drop; f < pf_n; ++f) {
-                                    sh.pf_pos[f - drop] = sh.pf_pos[f];
-                                    sh.pf_msg[f - drop] = sh.pf_msg[f];
-                                    sh.pf_pi[f - drop] = sh.pf_pi[f];
-                                    sh.pf_val[3 * (f - drop)] = sh.pf_val[3 * f];
-                                    sh.pf_val[3 * (f - drop) + 1] = sh.pf_val[3 * f + 1];
-                                    sh.pf_val[3 * (f - drop) + 2] = sh.pf_val[3 * f + 2];
-                                }
-                            pf_n -= drop;
-                            w2_lds_done();
-                        }
-                    }
-                }
+    if (decider) publish(RT_ADVANCE, 0u, 0u, 0u, Sx0, 0u, 0u, 0.0, 0.0, 0.0, 0.0, 0.0); // record 0: the first window
+
+    for (;;) {
+        // =================================================================================================================
+        // every chain wave: take the record, bring the slot up to date, test it, answer with the candidate mask
+        // =================================================================================================================
+        if (!decider) {
+            uint32_t seen = 0;
+            if (!wait_seen(seen, S_RECSEQ, rno + 1u)) break;
+        }
+        const W2_LDS uint32_t* rc = sh.rec + (rno % W2_NREC) * R_WORDS;
+        const uint32_t r_type = w2_uni(rc[R_TYPE]);
+        if (r_type == (uint32_t)RT_END) break;
+        const uint32_t r_q = w2_uni(rc[R_Q]), r_cn = w2_uni(rc[R_CN]), r_sxo = w2_uni(rc[R_SXO]), r_sxn = w2_uni(rc[R_SXN]), r_fd = w2_uni(rc[R_FD]);
+        const uint32_t r_pfn = w2_uni(rc[R_PFN]);
+        if (r_type == (uint32_t)RT_PIVOT) {
+            // a predicted pivot: its Gram term with this column came with the column's dot.  Columns whose dot was here before this record
+            // take the correction now; the others find the pivot on the list of fired ones when their dot is absorbed (below, or later)
+            const uint32_t jo = pos_of_slot(sl, C);
+            const double db = *(const W2_LDS double*)(rc + R_DB), mq = *(const W2_LDS double*)(rc + R_MQ), sq = *(const W2_LDS double*)(rc + R_SQ);
+            const bool hit = son && jo > r_q && jo < Fs;
+            const uint32_t piq = rc[R_PIQ];
+            const double A = (double)sh.wpt[sl * RS_PMAX + (hit ? (piq - spi) & 3u : 0u)];
+            const double xx = mstd * sq * (A - n_total * (mave * mq));
+            dp = hit ? dp + db * xx : dp;
+        }
+        // the dots that have arrived: positions [Fs, r_fd) -- with the corrections of the pivots that fired between a column's streaming
+        // and now (their updates were not in the streamed dot; the terms came with it)
+        {
+            const uint32_t j = pos_of_slot(sl, C);
+            const bool arr = son && j >= Fs && j < r_fd;
+            const double dnew = sh.dpr[sl];
+            dpr = arr ? dnew : dpr;
+            for (uint32_t f = 0; f < r_pfn; ++f) { // (uniform, rarely any)
+                const uint32_t fmsg = sh.pf_msg[f], fpos = sh.pf_pos[f], fpi = sh.pf_pi[f];
+                const double fdb = sh.pf_val[3 * f], fmv = sh.pf_val[3 * f + 1], fsd = sh.pf_val[3 * f + 2];
+                const bool hit = arr && fmsg > sbt && fpos < j;
+                const double A = (double)sh.wpt[sl * RS_PMAX + (hit ? (fpi - spi) & 3u : 0u)];
+                const double xx = mstd * fsd * (A - n_total * (mave * fmv));
+                dp = hit ? dp + fdb * xx : dp;
             }
-            lap(5);
-            if (base >= Fs) {
-                if (base >= Sx) break; // the whole window has been walked: a round that only advances
-                // the walk needs dots that are still on their way
-                ++n_refold;
-                if (!wait_seen(fpub_seen, S_FPUB, Fs + 1u)) {
+            Fs = r_fd > Fs ? r_fd : Fs;
+        }
+        if (r_type != (uint32_t)RT_EXTEND) {
+            const uint32_t jo = pos_of_slot(sl, C); // the slot's position in the window as it was
+            const double db = *(const W2_LDS double*)(rc + R_DB), mq = *(const W2_LDS double*)(rc + R_MQ), sq = *(const W2_LDS double*)(rc + R_SQ);
+            if (r_type == (uint32_t)RT_EVENT) {
+                // an event that took the round trip: the streaming workgroups' Gram terms of this slot's column, all shard rows; every word
+                // must carry its shard's full arrival count
+                const uint32_t par = (w2_uni(rc[R_NEV]) - 1u) & 1u;
+                const bool hit = son && jo > r_q && jo < r_sxo;
+                const unsigned long long t0 = wall_clock64();
+                bool bad = false;
+                if constexpr (MISS) {
+                    const unsigned long long* wp = gacc64 + (size_t)par * RS_NSH * RS_GROW + sl;
+                    unsigned long long A = 0ull;
+                    if (hit) {
+                        unsigned long long v[RS_NSH];
+                        for (;;) {
+#pragma unroll
+                            for (int r = 0; r < RS_NSH; ++r) v[r] = (uint32_t)r < nsh ? __hip_atomic_load(wp + (size_t)r * RS_GROW, HG_RLX_AGENT) : 0ull;
+                            bool ok = true;
+#pragma unroll
+                            for (int r = 0; r < RS_NSH; ++r) {
+                                const unsigned long long pa = gpa64[r], pb = gpb64[r];
+                                const unsigned long long d = v[r] - (par ? pb : pa);
+                                ok = ok && ((uint32_t)r >= nsh || (d >> 56) == cntG[(uint32_t)r < W % nsh ? 0 : 1]);
+                            }
+                            if (ok) break;
+                            if (wall_clock64() - t0 > timeout || aborted()) {
+                                bad = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int r = 0; r < RS_NSH; ++r) {
+                            const unsigned long long pa = gpa64[r], pb = gpb64[r];
+                            const unsigned long long d = v[r] - (par ? pb : pa);
+                            A += d & (RS_ONE64 - 1ull);
+                            gpa64[r] = par ? pa : v[r];
+                            gpb64[r] = par ? v[r] : pb;
+                        }
+                    }
+                    const double gsq = *(const W2_LDS double*)(rc + R_GSQ), nmq = *(const W2_LDS double*)(rc + R_NMQ);
+                    const double Ad = (double)A * (1.0 / (double)(1ull << RS_GFX));
+                    const double both = n_total - nms - nmq; // + X: calls present in both columns
+                    const double xx = mstd * sq * (((Ad - mq * gsm) - mave * gsq) + (mave * mq) * both);
+                    dp = hit ? dp + db * xx : dp;
+                } else {
+                    const uint32_t* wp = gacc + (size_t)par * RS_NSH * RS_GROW + sl;
+                    uint32_t A = 0u;
+                    if (hit) {
+                        uint32_t v[RS_NSH];
+                        for (;;) {
+#pragma unroll
+                            for (int r = 0; r < RS_NSH; ++r) v[r] = (uint32_t)r < nsh ? __hip_atomic_load(wp + (size_t)r * RS_GROW, HG_RLX_AGENT) : 0u;
+                            bool ok = true;
+#pragma unroll
+                            for (int r = 0; r < RS_NSH; ++r) {
+                                const uint32_t pa = gpa32[r], pb = gpb32[r];
+                                const uint32_t d = v[r] - (par ? pb : pa);
+                                ok = ok && ((uint32_t)r >= nsh || (d >> 24) == cntG[(uint32_t)r < W % nsh ? 0 : 1]);
+                            }
+                            if (ok) break;
+                            if (wall_clock64() - t0 > timeout || aborted()) {
+                                bad = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int r = 0; r < RS_NSH; ++r) {
+                            const uint32_t pa = gpa32[r], pb = gpb32[r];
+                            const uint32_t d = v[r] - (par ? pb : pa);
+                            A += d & RS_LOW;
+                            gpa32[r] = par ? pa : v[r];
+                            gpb32[r] = par ? v[r] : pb;
+                        }
+                    }
+                    const double xx = mstd * sq * ((double)A - n_total * (mave * mq));
+                    dp = hit ? dp + db * xx : dp;
+                }
+                if (__ballot(bad) != 0ull) {
+                    if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
+                    break;
+                }
+                if (DBG && decider && lane == 0) w2_gst(trace + (1 * RS_TRACE + w2_uni(rc[R_SEQ]) % RS_TRACE), wall_clock64());
+            }
+            // the window moves: the slots of the consumed positions take the positions [r_sxo, r_sxn)
+            if (r_sxn > r_sxo) {
+                uint32_t seen = mpub_seen;
+                if (!wait_seen(seen, S_MPUB, r_sxn)) break;
+                mpub_seen = seen;
+                const uint32_t jn = pos_of_slot(sl, r_cn);
+                const bool take = son && jn >= r_sxo && jn < r_sxn;
+                const uint32_t ms = (take ? jn : 0u) & mrmask;
+                const double a = sh.mave[ms], d = sh.mstd[ms], b = sh.bold[ms];
+                const int g = sh.ga[ms] & 0x0fffffff;
+                const double sc = sh.fscale[g];
+                const uint32_t bno = rc[R_SEQ], bpi = rc[R_PIN];
+                mave = take ? a : mave;
+                mstd = take ? d : mstd;
+                boldn = take ? b * n_minus_1 : boldn;
+                prd = take ? b != 0.0 : prd;
+                fsc = take ? sc : fsc;
+                fof = take ? (uint32_t)g * (uint32_t)(RS_FN + 1) : fof;
+                dp = take ? 0.0 : dp;
+                dpr = take ? 0.0 : dpr;
+                sbt = take ? bno : sbt;
+                spi = take ? bpi : spi;
+                if constexpr (MISS) {
+                    const double gs = sh.gsum[ms], nm = sh.nmis[ms];
+                    gsm = take ? gs : gsm;
+                    nms = take ? nm : nms;
+                }
+                if (take) sh.batch[sl] = bno;
+            }
+            C = r_cn;
+            Sx = r_sxn;
+            base = r_cn;
+            gposr = w2_uni(rc[R_GPOSR]);
+        }
+        // ---- the bound test of the positions [base, Fs): "this marker cannot be an event" (a candidate else); the numerator goes to the
+        // results ring as it stands -- final once the position is consumed ----
+        unsigned long long mymask;
+        {
+            const uint32_t j = pos_of_slot(sl, C);
+            const bool act = son && j >= base && j < Fs;
+            const double num = (dpr + dp) + boldn;
+            if (act) sh.rnum[j & (W2_RR - 1u)] = num;
+            const double x = (num * num) * fsc;
+            const bool inside = x < (double)RS_FN && fsc > 0.0; // (NaN: outside)
+            const int kx = inside ? (int)x : 0;
+            uint32_t r = gposr + ((j - C) & bmask);
+            r = r >= W2_RING ? r - W2_RING : r;
+            const double f0 = sh.ftab[fof + (uint32_t)kx], f1 = sh.ftab[fof + (uint32_t)kx + 1u], tqv = sh.tq[r];
+            const double fup = f0 + (x - (double)kx) * (f1 - f0);
+            mymask = __ballot(act && (prd || !(inside && fup <= tqv)));
+        }
+        base = Fs;
+        if (!decider) {
+            if (lane == 0) *(W2_LDS u4_t*)(sh.ans + 4 * wave) = rs_u4((uint32_t)mymask, (uint32_t)(mymask >> 32), rno + 1u, 0u); // (one 16-byte store: mask and number together)
+            ++rno;
+            continue;
+        }
+        ++rno;
+        lap(5);
+        // =================================================================================================================
+        // the decider: the other waves' answers, the first candidate in window order, the exact decision, the next record
+        // =================================================================================================================
+        if (r_type != (uint32_t)RT_EXTEND) cm[0] = cm[1] = cm[2] = cm[3] = 0ull;
+        cm[0] |= mymask;
+        if (nch > 1u) { // the other waves' answers: all three entries in one round trip, again until each carries this record's number
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                const u4_t a1 = *(const volatile W2_LDS u4_t*)(sh.ans + 4), a2 = *(const volatile W2_LDS u4_t*)(sh.ans + 8), a3 = *(const volatile W2_LDS u4_t*)(sh.ans + 12);
+                const bool ok = w2_uni(a1.z) == rno && (nch < 3u || (w2_uni(a2.z) == rno && w2_uni(a3.z) == rno));
+                if (ok) {
+                    cm[1] |= ((unsigned long long)w2_uni(a1.y) << 32) | w2_uni(a1.x);
+                    if (nch >= 3u) {
+                        cm[2] |= ((unsigned long long)w2_uni(a2.y) << 32) | w2_uni(a2.x);
+                        cm[3] |= ((unsigned long long)w2_uni(a3.y) << 32) | w2_uni(a3.x);
+                    }
+                    break;
+                }
+                if (spin_fail(t0)) {
                     failed = true;
                     break;
                 }
-                lap(0);
-                continue;
             }
-            // ---- the bound test of the positions [base, Fs): "this marker cannot be an event" ----
-            ++n_chunks;
-            unsigned long long cm[4];
-            {
-                bool act[4], inside[4];
-                double x[4], tqv[4], f0[4], f1[4];
-                int kx[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t j = pos_of_slot(sl[i], C);
-                    act[i] = son[i] && j >= base && j < Fs;
-                    const double num = (dpr[i] + dp[i]) + boldn[i];
-                    if (act[i]) sh.rnum[j & (W2_RR - 1u)] = num; // the numerator as last tested: final once the position is consumed
-                    x[i] = (num * num) * fsc[i];
-                    inside[i] = x[i] < (double)RS_FN && fsc[i] > 0.0; // (NaN: outside)
-                    kx[i] = inside[i] ? (int)x[i] : 0;
-                    uint32_t r = gposr + ((j - C) & bmask);
-                    r = r >= W2_RING ? r - W2_RING : r;
-                    f0[i] = sh.ftab[fof[i] + (uint32_t)kx[i]];
-                    f1[i] = sh.ftab[fof[i] + (uint32_t)kx[i] + 1u];
-                    tqv[i] = sh.tq[r];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double fup = f0[i] + (x[i] - (double)kx[i]) * (f1[i] - f0[i]);
-                    cm[i] = __ballot(act[i] && (prd[i] || !(inside[i] && fup <= tqv[i])));
+        }
+        if (failed) break;
+        lap(1);
+        if (lane == 0 && (DBG || (n_chunks & 255u) == 0u)) w2_gst(progress, ((unsigned long long)n_rounds << 8) | 1u);
+        // fired pivots stay on record only while a column streamed before their update is without its dot (entries are in message order).
+        // (The chain waves read the list while they take a record; it changes only here, behind their answers.)
+        if (pf_n) {
+            if (Fs >= Sx) pf_n = 0;
+            else {
+                const uint32_t bF = w2_uni(sh.batch[Fs & bmask]);
+                uint32_t drop = 0;
+                while (drop < pf_n && w2_uni(sh.pf_msg[drop]) <= bF) ++drop;
+                if (drop) {
+                    if (lane == 0)
+                        for (uint32_t f = drop; f < pf_n; ++f) {
+                            sh.pf_pos[f - drop] = sh.pf_pos[f];
+                            sh.pf_msg[f - drop] = sh.pf_msg[f];
+                            sh.pf_pi[f - drop] = sh.pf_pi[f];
+                            sh.pf_val[3 * (f - drop)] = sh.pf_val[3 * f];
+                            sh.pf_val[3 * (f - drop) + 1] = sh.pf_val[3 * f + 1];
+                            sh.pf_val[3 * (f - drop) + 2] = sh.pf_val[3 * f + 2];
+                        }
+                    pf_n -= drop;
+                    w2_lds_done();
                 }
             }
-            lap(2);
-            // ---- the candidates in window order, until one is an event ----
+        }
+        // the generator: the words a decision can reach exist
+        if (gpos + B + 96u > blk * (uint32_t)MT_N && !wait_seen(blk, S_BLK, (gpos + B + 96u + (uint32_t)MT_N - 1u) / (uint32_t)MT_N)) break;
+        ++n_chunks;
+        bool found = false;
+        uint32_t qpos = 0, q_consumed = 0;
+        int q_k = 0;
+        double q_bnew = 0.0, q_bold = 0.0;
+        {
             const uint32_t s0 = C & bmask, i0 = s0 >> 6, l0 = s0 & 63u;
             const unsigned long long lowm = (1ull << l0) - 1ull;
             for (;;) {
                 uint32_t qs = 0xffffffffu;
 #pragma unroll
-                for (int t = 0; t <= 4; ++t) {
-                    if ((uint32_t)t <= NSL && qs == 0xffffffffu) {
+                for (int t = 0; t <= W2_NCH; ++t) {
+                    if ((uint32_t)t <= nch && qs == 0xffffffffu) {
                         uint32_t i = i0 + (uint32_t)t;
-                        i = i >= NSL ? i - NSL : i;
+                        i = i >= nch ? i - nch : i;
                         unsigned long long mm = i == 0u ? cm[0] : (i == 1u ? cm[1] : (i == 2u ? cm[2] : cm[3]));
                         if (t == 0) mm &= ~lowm;
-                        if ((uint32_t)t == NSL) mm &= lowm;
+                        if ((uint32_t)t == nch) mm &= lowm;
                         if (mm) qs = i * 64u + (uint32_t)(__ffsll((long long)mm) - 1);
                     }
                 }
@@ -470,10 +621,10 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 uint32_t upos = gposr + (qc - C);
                 upos = upos >= W2_RING ? upos - W2_RING : upos;
                 // (one round trip for all of the candidate's values)
-                const double bold_v = sh.bold[ms], num_v = sh.rnum[qc & (W2_RR - 1u)];
+                const double bold_v = sh.bold[ms], num = sh.rnum[qc & (W2_RR - 1u)];
                 const int ga_v = sh.ga[ms];
                 const uint32_t word_v = sh.mt[upos];
-                const double bold = w2_uni(bold_v), num = num_v;
+                const double bold = w2_uni(bold_v);
                 const int g0 = w2_uni(ga_v & 0x0fffffff) * K;
                 const double prob = (double)mt_temper(word_v) * (1.0 / 4294967296.0);
                 // a5 (src/BayesRRm.cpp:1859-1921) over the lanes: lane x < K holds logL_x; lane 8 kk + l the term exp(logL_l - logL_kk)
@@ -549,12 +700,17 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 else if (qi == 2u) cm[2] &= ~bit;
                 else cm[3] &= ~bit;
             }
-            lap(3);
-            if (found || failed) break;
-            base = Fs; // every position below has passed; on to the dots still to come
         }
+        lap(3);
         if (failed) break;
-
+        if (!found && Fs < Sx) {
+            // every position with a dot has passed: the walk needs dots that are still on their way
+            ++n_refold;
+            if (!wait_seen(fpub_seen, S_FPUB, Fs + 1u)) break;
+            lap(0);
+            publish(RT_EXTEND, 0u, C, Sx, Sx, fpub_seen < Sx ? fpub_seen : Sx, 0u, 0.0, 0.0, 0.0, 0.0, 0.0);
+            continue;
+        }
         // ---- the message: an event at qpos, or a round that only moves the window on ----
         const uint32_t ncons = found ? qpos - C + 1u : Sx - C;
         const uint32_t Cn = C + ncons;
@@ -562,19 +718,17 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         const double dbeta = found ? q_bold - q_bnew : 0.0;
         const bool is_event = found && dbeta != 0.0;
         const bool predicted = found && q_bold != 0.0;
-        const uint32_t qms = (found ? qpos : C) & mrmask;
-        const double mq_v = sh.mave[qms], sq_v = sh.mstd[qms], gsq_v = MISS ? sh.gsum[qms] : 0.0, nmq_v = MISS ? sh.nmis[qms] : 0.0;
-        const uint32_t blo_v = sh.batch[(qpos + 1u) & bmask]; // (the oldest batch with columns behind the event, if there are any)
         // a predicted pivot whose Gram terms came with the columns: the oldest batch with columns behind it lists it
         bool pivot = false;
         if (pivots && is_event && predicted && pf_n < (uint32_t)RS_PFIRE)
-            pivot = qpos + 1u >= Sx || pi - w2_uni(sh.bl_pi[w2_uni(blo_v) % W2_NB]) < (uint32_t)RS_PMAX;
+            pivot = qpos + 1u >= Sx || pi - w2_uni(sh.bl_pi[w2_uni(sh.batch[(qpos + 1u) & bmask]) % W2_NB]) < (uint32_t)RS_PMAX;
         // flow control: never more than RS_MSG - 3 messages ahead of the slowest streaming workgroup (batches completed = messages
         // taken + 1); room in the results ring and on the event record
         if (seq + 6u > (uint32_t)RS_MSG && !wait_seen(rdone_seen, S_RDONE, seq + 6u - (uint32_t)RS_MSG)) break;
         if (Cn + B > W2_RR && !wait_seen(wpub_seen, S_WPUB, Cn + B - W2_RR)) break;
         if (evn + 2u > W2_EV && !wait_seen(evw_seen, S_EVW, evn + 2u - W2_EV)) break;
         ++seq;
+        ++n_rounds;
         if (lane == 0) {
             const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE)) | (Cn >= M ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
@@ -582,21 +736,17 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 w2_gst(trace + (2 * RS_TRACE + (seq - 1u) % RS_TRACE), wall_clock64());
                 w2_gst(trace + (3 * RS_TRACE + (seq - 1u) % RS_TRACE), ncons);
                 w2_gst(trace + (0 * RS_TRACE + seq % RS_TRACE), wall_clock64());
+                if (!(is_event && !pivot)) w2_gst(trace + (1 * RS_TRACE + seq % RS_TRACE), wall_clock64());
             }
             rs_store16(msg + (seq % RS_MSG), rs_u4(rs_msg_word0(kf, ncons, seq, (uint32_t)db, (uint32_t)(db >> 32)), seq, (uint32_t)db, (uint32_t)(db >> 32)));
         }
         const bool round_trip = is_event && !pivot;
-        const uint32_t gV = found ? Sx - (qpos + 1u) : 0u;
-        if (round_trip) {
-            ++nev;
-            if (gV && lane == 0) {
-                sh.sw[S_GV] = gV;
-                w2_lds_done();
-                w2_st(sh.sw + S_GREQ, nev);
-            }
-        }
+        if (round_trip) ++nev;
+        // (behind the message: what only the record needs)
+        const uint32_t qms = (found ? qpos : C) & mrmask;
+        const double mq_v = sh.mave[qms], sq_v = sh.mstd[qms], gsq_v = MISS ? sh.gsum[qms] : 0.0, nmq_v = MISS ? sh.nmis[qms] : 0.0;
         const double mq = w2_uni(mq_v), sq = w2_uni(sq_v), gsq = w2_uni(gsq_v), nmq = w2_uni(nmq_v);
-        // ---- results of the consumed positions [C, Cn): their numerators are in the ring (the bound test left them there); the event on record ----
+        // the event on record (the consumed positions' numerators are in the results ring: the bound test left them there)
         if (found) {
             if (lane == 0) {
                 sh.ev_pos[evn % W2_EV] = qpos;
@@ -611,19 +761,13 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             if (predicted) ++n_pred;
         } else
             ++n_adv;
-        // ---- a pivot's corrections: the terms are here ----
+        const uint32_t piq = pi;
+        // dots that are here by now may be absorbed with this record
+        fpub_seen = w2_ld(sh.sw + S_FPUB);
+        const uint32_t Fd = fpub_seen < Sx ? fpub_seen : Sx;
         if (pivot) {
             ++n_pivots;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t j = pos_of_slot(sl[i], C);
-                const bool hit = son[i] && j > qpos && j < Fs;
-                const uint32_t ip = hit ? (pi - spi[i]) & 3u : 0u;
-                const double A = (double)sh.wpt[sl[i] * RS_PMAX + ip];
-                const double xx = mstd[i] * sq * (A - n_total * (mave[i] * mq));
-                dp[i] = hit ? dp[i] + dbeta * xx : dp[i];
-            }
-            if (Fs < Sx) { // columns behind the event whose dot (streamed before this update) is still on its way
+            if (Fs < Sx) { // columns behind the event whose dot (streamed before this update) has not been absorbed: the correction waits for it
                 if (lane == 0) {
                     sh.pf_pos[pf_n] = qpos;
                     sh.pf_msg[pf_n] = seq;
@@ -636,17 +780,6 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             }
         }
         if (predicted) ++pi;
-        // ---- the window moves: the slots of the consumed positions take the positions [Sx, Sn) ----
-        if (Sn > Sx) {
-            if (!wait_seen(mpub_seen, S_MPUB, Sn)) break;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t j = pos_of_slot(sl[i], Cn);
-                const bool take = son[i] && j >= Sx && j < Sn;
-                take_meta(i, j, take, seq, pi);
-                if (take) sh.batch[sl[i]] = seq;
-            }
-        }
         if (lane == 0) { // this batch's pivots: the first predicted positions of the window [Cn, Sn)
             uint32_t np = 0, p0 = 0xffffffffu;
             if (pivots) {
@@ -657,85 +790,55 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             sh.bl_pi[seq % W2_NB] = pi;
             sh.bl_np[seq % W2_NB] = np;
             sh.bl_p0[seq % W2_NB] = p0;
+            sh.bl_sn[seq % W2_NB] = Sn;
         }
         // the generator moves past the consumed positions' uniforms and the draw
-        {
-            const uint32_t adv = ncons + q_consumed;
-            gpos += adv;
-            gposr += adv;
-            while (gposr >= W2_RING) gposr -= W2_RING;
-        }
+        gpos += ncons + q_consumed;
         w2_lds_done();
         if (lane == 0) {
-            w2_st(sh.sw + S_SXPUB, Sn);
+            w2_st(sh.sw + S_SEQPUB, seq);
             w2_st(sh.sw + S_EVN, evn); // (before the cursor: the housekeeper reads the cursor first)
             w2_st(sh.sw + S_CPUB, Cn);
             w2_st(sh.sw + S_GPOS, gpos);
             w2_st(sh.sw + S_PCUR, pi);
         }
+        if (Cn >= M) { // the sweep is over
+            C = Cn;
+            break;
+        }
+        // the record: what happened, for every chain wave (this one included)
+        publish(found ? (pivot ? (uint32_t)RT_PIVOT : (is_event ? (uint32_t)RT_EVENT : (uint32_t)RT_ADVANCE)) : (uint32_t)RT_ADVANCE, found ? qpos : Cn - 1u, Cn, Sx, Sn, Fd, piq, dbeta,
+                mq, sq, gsq, nmq);
         lap(4);
-        // ---- an event that needs the round trip: the collectors' sums, then its corrections ----
-        if (round_trip && gV) {
-            const uint32_t ncl = nsh < (uint32_t)W2_NCOL ? nsh : (uint32_t)W2_NCOL;
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < W2_NCOL; ++c)
-                if ((uint32_t)c < ncl && ok) ok = wait_seen(gdone_seen[c], S_GDONE + c, nev);
-            if (!ok) break;
-            lap(1);
-            if (DBG && lane == 0) w2_gst(trace + (1 * RS_TRACE + seq % RS_TRACE), wall_clock64());
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t j = pos_of_slot(sl[i], Cn);
-                const bool hit = son[i] && j < Sx; // the old window's positions behind the event
-                const uint32_t c = hit ? j - Cn : 0u;
-                if constexpr (MISS) {
-                    unsigned long long A = sh.gpart64[c];
-#pragma unroll
-                    for (int w = 1; w < W2_NCOL; ++w) A += (uint32_t)w < ncl ? sh.gpart64[(uint32_t)w * RS_BMAX + c] : 0ull;
-                    const double Ad = (double)A * (1.0 / (double)(1ull << RS_GFX));
-                    const double both = n_total - nms[i] - nmq; // + X: calls present in both columns
-                    const double xx = mstd[i] * sq * (((Ad - mq * gsm[i]) - mave[i] * gsq) + (mave[i] * mq) * both);
-                    dp[i] = hit ? dp[i] + dbeta * xx : dp[i];
-                } else {
-                    uint32_t A = gpart[c];
-#pragma unroll
-                    for (int w = 1; w < W2_NCOL; ++w) A += (uint32_t)w < ncl ? gpart[(uint32_t)w * RS_BMAX + c] : 0u;
-                    const double xx = mstd[i] * sq * ((double)A - n_total * (mave[i] * mq));
-                    dp[i] = hit ? dp[i] + dbeta * xx : dp[i];
-                }
-            }
-        } else if (DBG && lane == 0)
-            w2_gst(trace + (1 * RS_TRACE + seq % RS_TRACE), wall_clock64());
-        C = Cn;
-        Sx = Sn;
-        base = Cn;
         // the staged list of predicted positions reaches far enough (the housekeeper refills behind S_PCUR)
         if (pivots && !wait_seen(pld_seen, S_PLD, pi + 8u)) break;
     }
-    if (C < M) { // the sweep was given up
-        ++seq;
-        if (lane == 0) {
-            w2_st(sh.sw + S_ABORT, 1u);
-            rs_store16(msg + (seq % RS_MSG), rs_u4(rs_msg_word0((uint32_t)RS_ABORT, 0u, seq, 0u, 0u), seq, 0u, 0u));
-            atomicMax(&state->error, err ? err : 3u);
+    if (decider) {
+        if (C < M) { // the sweep was given up
+            ++seq;
+            if (lane == 0) {
+                w2_st(sh.sw + S_ABORT, 1u);
+                rs_store16(msg + (seq % RS_MSG), rs_u4(rs_msg_word0((uint32_t)RS_ABORT, 0u, seq, 0u, 0u), seq, 0u, 0u));
+                atomicMax(&state->error, err ? err : 3u);
+            }
         }
-    }
-    if (lane == 0) {
-        w2_st(sh.sw + S_GPOS, gpos);
-        w2_lds_done();
-        w2_st(sh.sw + S_END, 1u);
-        state->cursor = C;
-        state->rounds = n_rounds;
-        state->events = n_events;
-        state->advances = n_adv;
-        state->nnz = n_nnz;
-        state->chunks = n_chunks;
-        state->refolds = n_refold;
-        state->pivots = n_pivots;
-        state->predicted = n_pred;
-        if (DBG)
-            for (int i = 0; i < 8; ++i) state->t[i] = tacc[i];
+        publish(RT_END, 0u, C, Sx, Sx, 0u, 0u, 0.0, 0.0, 0.0, 0.0, 0.0);
+        if (lane == 0) {
+            w2_st(sh.sw + S_GPOS, gpos);
+            w2_lds_done();
+            w2_st(sh.sw + S_END, 1u);
+            state->cursor = C;
+            state->rounds = n_rounds;
+            state->events = n_events;
+            state->advances = n_adv;
+            state->nnz = n_nnz;
+            state->chunks = n_chunks;
+            state->refolds = n_refold;
+            state->pivots = n_pivots;
+            state->predicted = n_pred;
+            if (DBG)
+                for (int i = 0; i < 8; ++i) state->t[i] = tacc[i];
+        }
     }
 }
 
@@ -746,7 +849,7 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
     // =====================================================================================================================
     // the folder: fixed-point sums of completed refill batches -> dots
     // =====================================================================================================================
-    uint32_t Ff = 0, done = 0;
+    uint32_t Ff = 0, done = 0, fb = 0; // fb: the refill batch of position Ff (batch b = the positions [bl_sn[b - 1], bl_sn[b]) announced by message b)
     unsigned long long t_idle = wall_clock64();
     auto poll_done = [&]() {
         uint32_t b = 0xffffffffu;
@@ -764,17 +867,18 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
     unsigned long long* const pacc = pr.pacc;
     for (;;) {
         if (ended() || aborted()) break;
-        const uint32_t sx = w2_ld(sh.sw + S_SXPUB);
-        if (Ff >= sx) { // nothing announced that has no dot: keep the batch count fresh for the chain's flow control
+        const uint32_t sq = w2_ld(sh.sw + S_SEQPUB);                 // messages posted
+        const uint32_t sx = w2_uni(sh.bl_sn[sq % W2_NB]);             // positions announced
+        while (fb < sq && Ff >= w2_uni(sh.bl_sn[fb % W2_NB])) ++fb;   // (batches without positions of their own are skipped)
+        if (Ff >= sx) { // nothing announced that has no dot: keep the batch count fresh for the decider's flow control
             poll_done();
             __builtin_amdgcn_s_sleep(2);
             t_idle = wall_clock64();
             continue;
         }
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.batch[Ff & bmask]);
-        if (done <= b0) {
+        if (done <= fb) {
             poll_done();
-            if (done <= b0) {
+            if (done <= fb) {
                 if (wall_clock64() - t_idle > timeout) {
                     if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
                     break;
@@ -786,7 +890,8 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
         // up to 64 positions from Ff on whose batch is complete (batches are in position order: a prefix)
         const uint32_t j = Ff + (uint32_t)lane;
         const uint32_t slot = j & bmask;
-        const uint32_t bt = j < sx ? sh.batch[slot] : 0xffffffffu;
+        uint32_t bt = fb;
+        while (bt < sq && j >= sh.bl_sn[bt % W2_NB]) ++bt; // (per lane: the 64 positions may span a few batches)
         const bool ok = j < sx && bt < done;
         if (ok) {
             const uint32_t rr = j % RS_RB;
@@ -949,124 +1054,6 @@ __device__ __attribute__((noinline)) void w2_housekeeper(const ResParams& pr)
     }
 }
 
-template <int MISS>
-__device__ __attribute__((noinline)) void w2_collector(const ResParams& pr)
-{
-    W2_PROLOGUE
-    // =====================================================================================================================
-    // the collectors: Gram terms of the window columns behind an event, rows c and c + 4 of the accumulator shards; wave s polls its
-    // rows, 16 bytes per lane; every word in use must carry the shard's full arrival count.  The words only ever grow (no store ever
-    // touches them: adds are performed at the memory side, and a store could overtake or be overtaken by one): what an event added is
-    // the difference to what the lane saw last time, per parity
-    // =====================================================================================================================
-    const uint32_t c = (uint32_t)wave - 4u;
-    uint32_t done_ev = 0;
-    u4_t gp0[2] = {rs_u4(0u, 0u, 0u, 0u), rs_u4(0u, 0u, 0u, 0u)}, gp1[2] = {rs_u4(0u, 0u, 0u, 0u), rs_u4(0u, 0u, 0u, 0u)}; // [row] by parity 0 / 1
-    unsigned long long gq0[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}}, gq1[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
-    const uint32_t* const gacc = pr.gacc;
-    const unsigned long long* const gacc64 = pr.gacc64;
-    for (;;) {
-        if (ended() || aborted()) break;
-        const uint32_t req = w2_ld(sh.sw + S_GREQ);
-        if (req == done_ev) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const uint32_t gV = w2_ld(sh.sw + S_GV);
-        const uint32_t par = (req - 1u) & 1u;
-        const bool mine = 4u * (uint32_t)lane < gV;
-        const unsigned long long t0 = wall_clock64();
-        bool fail = false;
-        if constexpr (MISS) {
-            unsigned long long acc[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-            for (int rw = 0; rw < 2; ++rw) {
-                const uint32_t row = c + 4u * (uint32_t)rw;
-                if (row < nsh && mine) { // (uniform in row; lanes beyond the columns have nothing to wait for)
-                    const unsigned long long* rp = gacc64 + ((size_t)par * RS_NSH + row) * RS_GROW + 4u * (uint32_t)lane;
-                    const unsigned long long want = cntG[row < W % nsh ? 0 : 1];
-                    unsigned long long v[4], d[4];
-                    for (;;) {
-                        const u4_t a = rs_load16(rp), b = rs_load16(rp + 2);
-                        v[0] = ((unsigned long long)a.y << 32) | a.x;
-                        v[1] = ((unsigned long long)a.w << 32) | a.z;
-                        v[2] = ((unsigned long long)b.y << 32) | b.x;
-                        v[3] = ((unsigned long long)b.w << 32) | b.z;
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            d[i] = v[i] - (par ? gq1[rw][i] : gq0[rw][i]);
-                            ok = ok && (4u * (uint32_t)lane + (uint32_t)i >= gV || (d[i] >> 56) == want);
-                        }
-                        if (ok) break;
-                        if (wall_clock64() - t0 > timeout || aborted()) {
-                            fail = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (par) gq1[rw][i] = v[i];
-                        else gq0[rw][i] = v[i];
-                        acc[i] += d[i] & (RS_ONE64 - 1ull);
-                    }
-                }
-            }
-            if (mine) {
-                W2_LDS unsigned long long* g64 = sh.gpart64 + c * RS_BMAX + 4u * (uint32_t)lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g64[i] = acc[i];
-            }
-        } else {
-            uint32_t acc[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int rw = 0; rw < 2; ++rw) {
-                const uint32_t row = c + 4u * (uint32_t)rw;
-                if (row < nsh && mine) {
-                    const uint32_t* rp = gacc + ((size_t)par * RS_NSH + row) * RS_GROW + 4u * (uint32_t)lane;
-                    const uint32_t want = cntG[row < W % nsh ? 0 : 1];
-                    u4_t v, d;
-                    for (;;) {
-                        v = rs_load16(rp);
-                        d = par ? (v - gp1[rw]) : (v - gp0[rw]);
-                        const uint32_t i = 4u * (uint32_t)lane;
-                        const bool ok = (d.x >> 24) == want && (i + 1u >= gV || (d.y >> 24) == want) && (i + 2u >= gV || (d.z >> 24) == want) &&
-                                        (i + 3u >= gV || (d.w >> 24) == want);
-                        if (ok) break;
-                        if (wall_clock64() - t0 > timeout || aborted()) {
-                            fail = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    // (a word beyond gV got no add this time: its difference is zero and its previous value stays what it is)
-                    if (par) gp1[rw] = v;
-                    else gp0[rw] = v;
-                    acc[0] += d.x & RS_LOW;
-                    acc[1] += d.y & RS_LOW;
-                    acc[2] += d.z & RS_LOW;
-                    acc[3] += d.w & RS_LOW;
-                }
-            }
-            if (mine) {
-                W2_LDS uint32_t* gp = gpart + c * RS_BMAX + 4u * (uint32_t)lane;
-                gp[0] = acc[0];
-                gp[1] = acc[1];
-                gp[2] = acc[2];
-                gp[3] = acc[3];
-            }
-        }
-        if (__ballot(fail) != 0ull) {
-            if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
-            break;
-        }
-        w2_lds_done();
-        done_ev = req;
-        if (lane == 0) w2_st(sh.sw + S_GDONE + (int)c, req);
-    }
-}
-
 template <int DBG, int MISS>
 __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
 {
@@ -1092,6 +1079,7 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
         sh.pprev[RS_RB + i] = 0ull;
     }
     if (tid < S_NWORDS) sh.sw[tid] = 0u;
+    if (tid < W2_NCH * 4) sh.ans[tid] = 0u;
     // metadata of the first two windows, the predicted positions, the first batch
     for (uint32_t j = (uint32_t)tid; j < m0; j += RS_BLOCK) stage_meta(j);
     for (uint32_t i = (uint32_t)tid; i < W2_PRED; i += RS_BLOCK) sh.pred[i] = i < M + 16u ? gpred[i] : 0xffffffffu;
@@ -1122,7 +1110,7 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
     }
     if (tid == 0) {
         sh.sw[S_MPUB] = m0;
-        sh.sw[S_SXPUB] = Sx0;
+        sh.bl_sn[0] = Sx0;
         sh.sw[S_BLK] = 1u;
         sh.sw[S_GPOS] = rng_idx0;
         sh.sw[S_PLD] = W2_PRED;
@@ -1135,10 +1123,10 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
     }
     __syncthreads();
 
-    if (wave == 0) w2_chain<DBG, MISS>(pr);
-    else if (wave == 1) w2_folder<MISS>(pr);
-    else if (wave == 2) w2_housekeeper<MISS>(pr);
-    else if (wave >= 4 && (uint32_t)wave - 4u < nsh) w2_collector<MISS>(pr);
+    if (wave < W2_NCH) {
+        if ((uint32_t)wave < (B >= 64u ? B / 64u : 1u)) w2_chain<DBG, MISS>(pr);
+    } else if (wave == 4) w2_folder<MISS>(pr);
+    else if (wave == 5) w2_housekeeper<MISS>(pr);
     __syncthreads();
     // ---- the generator and the counters go back ----
     {

@@ -154,6 +154,7 @@ struct hgibbs_ctx {
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
     int res_walker = 0;       // option walker: 0 auto, 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
+    int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
     ResMsg* res_msg = nullptr;
@@ -1222,6 +1223,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         h->window = (uint32_t)value;
     } else if (!std::strcmp(name, "pivots")) {
         h->res_pivots = value != 0;
+    } else if (!std::strcmp(name, "res_tune")) {
+        h->res_tune = (int)value;
     } else if (!std::strcmp(name, "walker")) {
         if (value < 0 || value > 2) return fail("walker must be 0 (auto), 1 (first) or 2 (second)");
         h->res_walker = (int)value;
@@ -1403,9 +1406,12 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         // the second walker: every marker takes a uniform, the mixture tables and the tabulated bound fit its LDS, one rank
         const bool w2_ok = h->res_all_ada && p.GK <= HT_LDS && G <= RS_FG && p.nranks == 1;
         if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks)", RS_FG, HT_LDS);
-        p.walker = (h->res_walker == 2) ? 2 : 1; // (auto: the first walker -- the second is not faster yet)
+        static const int env_walker = std::getenv("HGIBBS_WALKER") ? std::atoi(std::getenv("HGIBBS_WALKER")) : 0; // (test runs: the default walker of handles that do not set the option)
+        const int want = h->res_walker ? h->res_walker : env_walker;
+        p.walker = (want == 2 && w2_ok) ? 2 : 1; // (auto: the first walker -- the second is not faster yet)
     }
     p.pred = h->pred;
+    p.tune = h->res_tune;
     {
         // the predicted events of this sweep, in sweep order (read by the streaming workgroups and by the walker)
         const uint32_t nchunk = (h->M + PRED_CHUNK - 1) / PRED_CHUNK;
