@@ -120,6 +120,9 @@ struct ResParams {
     unsigned long long timeout;  // 100 MHz ticks a spin may last
     unsigned long long* progress; // device memory: [0] walker (round << 8 | stage), [1] streaming workgroup 0 (message << 8 | stage): what the host
                                   // reports when its deadline passes (a store to host memory here would put a PCIe round trip in front of the next barrier)
+    // progress[2]: the host's abort word (non-zero: give the sweep up -- polled where a workgroup waits); progress[3]: workgroups that have
+    // arrived at the kernel's start (the rendezvous below)
+    unsigned long long rdv_timeout; // 100 MHz ticks the start-of-kernel rendezvous may last
     unsigned long long* trace;   // debug_timing: [8][RS_TRACE] wall-clock stamps of the last RS_TRACE messages (tools/res_anatomy.py)
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
@@ -378,6 +381,37 @@ __device__ __forceinline__ void fma_col(uint32_t g, const double (&e)[IPT], doub
 {
     (fma_col4<Q>(g, e, a0, a1, a2, a3), ...);
 }
+// The same for a whole dword (sixteen slots) as ONE instruction block -- between separate blocks the compiler pads with s_nop, and every
+// instruction a wave issues costs it the same four to five clocks -- and, where the dword is the column's first (FIRST), with the
+// accumulators STARTED by the first four products (v_mul_f64: no four moves of zero in front; the products are exact either way).
+template <bool FIRST>
+__device__ __forceinline__ void fma_dword(uint32_t g, const double (&e)[IPT], double& a0, double& a1, double& a2, double& a3)
+{
+    uint32_t t0, t1, t2, t3;
+    double w0, w1, w2, w3;
+#define HG_FD_BLOCK(S0, S1, S2, S3, E0, E1, E2, E3, OP)                                                                                    \
+    "v_bfe_u32 %[t0], %[g], " #S0 ", 2\n\tv_bfe_u32 %[t1], %[g], " #S1 ", 2\n\tv_bfe_u32 %[t2], %[g], " #S2 ", 2\n\tv_bfe_u32 %[t3], %[g], " #S3 ", 2\n\t"   \
+    "v_cvt_f64_u32 %[w0], %[t0]\n\tv_cvt_f64_u32 %[w1], %[t1]\n\tv_cvt_f64_u32 %[w2], %[t2]\n\tv_cvt_f64_u32 %[w3], %[t3]\n\t" OP(E0, E1, E2, E3)
+#define HG_FD_FMAC(E0, E1, E2, E3) "v_fmac_f64 %[a0], %[w0], %[" #E0 "]\n\tv_fmac_f64 %[a1], %[w1], %[" #E1 "]\n\tv_fmac_f64 %[a2], %[w2], %[" #E2 "]\n\tv_fmac_f64 %[a3], %[w3], %[" #E3 "]\n\t"
+#define HG_FD_MUL(E0, E1, E2, E3) "v_mul_f64 %[a0], %[w0], %[" #E0 "]\n\tv_mul_f64 %[a1], %[w1], %[" #E1 "]\n\tv_mul_f64 %[a2], %[w2], %[" #E2 "]\n\tv_mul_f64 %[a3], %[w3], %[" #E3 "]\n\t"
+#define HG_FD_OPERANDS                                                                                                                     \
+    [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)               \
+        : [g] "v"(g), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]), [e4] "v"(e[4]), [e5] "v"(e[5]), [e6] "v"(e[6]), [e7] "v"(e[7]), [e8] "v"(e[8]),  \
+          [e9] "v"(e[9]), [e10] "v"(e[10]), [e11] "v"(e[11]), [e12] "v"(e[12]), [e13] "v"(e[13]), [e14] "v"(e[14]), [e15] "v"(e[15])
+    if constexpr (FIRST) {
+        asm(HG_FD_BLOCK(0, 2, 4, 6, e0, e1, e2, e3, HG_FD_MUL) HG_FD_BLOCK(8, 10, 12, 14, e4, e5, e6, e7, HG_FD_FMAC) HG_FD_BLOCK(16, 18, 20, 22, e8, e9, e10, e11, HG_FD_FMAC)
+                HG_FD_BLOCK(24, 26, 28, 30, e12, e13, e14, e15, HG_FD_FMAC)
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), HG_FD_OPERANDS);
+    } else {
+        asm(HG_FD_BLOCK(0, 2, 4, 6, e0, e1, e2, e3, HG_FD_FMAC) HG_FD_BLOCK(8, 10, 12, 14, e4, e5, e6, e7, HG_FD_FMAC) HG_FD_BLOCK(16, 18, 20, 22, e8, e9, e10, e11, HG_FD_FMAC)
+                HG_FD_BLOCK(24, 26, 28, 30, e12, e13, e14, e15, HG_FD_FMAC)
+            : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), HG_FD_OPERANDS);
+    }
+#undef HG_FD_BLOCK
+#undef HG_FD_FMAC
+#undef HG_FD_MUL
+#undef HG_FD_OPERANDS
+}
 
 template <int T, int DBG, int MISS>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
@@ -455,7 +489,9 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         constexpr int r = decltype(rtag)::value;
         const uint32_t pn = __builtin_amdgcn_readfirstlane(pos_of(k));
         const int32_t mk = __builtin_amdgcn_readlane(ids, r);
-        rs_set_load<T, r>(voff, p.bed + (size_t)(pn < M ? mk : 0) * p.stride);
+        // (the stride is a multiple of 1 KiB and a shard's BED below 4 TiB -- resident_plan -- : one 32-bit multiply and a shift instead of a
+        // 64-bit multiply's four; scalar instructions cost the wave its issue slot like any other)
+        rs_set_load<T, r>(voff, p.bed + ((size_t)((uint32_t)(pn < M ? mk : 0) * (uint32_t)(p.stride >> 10)) << 10));
     };
     // lane r < RS_PF: (mave, mstd) of the column of position p1 and the id of position p2
     auto lane_load = [&](uint32_t p1, uint32_t p2) { rs_lane_load(p.s_mave + (p1 < M ? p1 : 0u), p.s_mstd + (p1 < M ? p1 : 0u), p.s_bold + (p1 < M ? p1 : 0u), p.order + (p2 < M ? p2 : 0u), p.s_ga + (p1 < M ? p1 : 0u)); };
@@ -620,7 +656,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 constexpr int r = decltype(rtag)::value;
                 const uint32_t kr = nk + (((uint32_t)r - nk) & (uint32_t)(RS_PF - 1));
                 if (kr - nk < m) { // wave-uniform
-                    double a[4] = {0.0, 0.0, 0.0, 0.0};
+                    double a[4];
+                    if constexpr (MISS) a[0] = a[1] = a[2] = a[3] = 0.0;
                     uint32_t gw[T];
                     rs_set_read<T, r>(gw, keep);
                     const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr));
@@ -669,8 +706,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                             part[(pos - Sx) * 2u + 1u] = w;
                         }
                     } else {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
+                    fma_dword<true>(gw[0], e[0], a[0], a[1], a[2], a[3]);
+                    if constexpr (T == 2) fma_dword<false>(gw[T - 1], e[T - 1], a[0], a[1], a[2], a[3]);
                     // the lane sums meet in eight-lane groups (three DPP steps, fixed order); the eight group sums go to LDS and
                     // are added by ONE thread per column behind the barrier (in order: the dot does not depend on which wave took it)
                     double v = (a[0] + a[1]) + (a[2] + a[3]);
@@ -808,11 +845,12 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         if (tid == 0) {
             const ResMsg* m = p.msg + (seq % RS_MSG);
             const unsigned long long t0 = wall_clock64();
+            uint32_t npoll = 0;
             u4_t v;
             for (;;) {
                 v = rs_load16(m);
                 if (v.y == seq && ((v.x >> 12) & 0xffffu) == rs_msg_check(seq, v.z, v.w)) break;
-                if (wall_clock64() - t0 > p.timeout) {
+                if (wall_clock64() - t0 > p.timeout || ((++npoll & 255u) == 0u && __hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull)) { // (or the host gave the sweep up)
                     v.x = (uint32_t)RS_ABORT << 28;
                     v.y = seq;
                     atomicMax(&p.state->error, 3u);
@@ -1876,6 +1914,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
 __global__ __launch_bounds__(256) void k_res_finish(ResParams p)
 {
     __shared__ int lc[256]; // GK <= 256 (resident_plan)
+    if (p.state->error != 0u) return; // the sweep was given up: the slots hold no numerators
     for (int i = threadIdx.x; i < 256; i += blockDim.x) lc[i] = 0;
     __syncthreads();
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1921,9 +1960,41 @@ __global__ __launch_bounds__(256) void k_res_finish(ResParams p)
 
 namespace hg {
 
+// Every workgroup of the grid waits for the others inside the sweep: all W + 1 must be resident at once.  The host checks that against
+// the occupancy query, which cannot see another process (or stream) on the device -- so the kernel makes sure itself, BEFORE it touches
+// eps, the effects or the generator: every workgroup counts itself in and waits, bounded, until all are there.  A grid that is only
+// partly resident ends here with error 6 and nothing written (hgibbs_sweep then runs the sweep on the batch engine).
+__device__ __forceinline__ bool rs_rendezvous(const ResParams& p, unsigned char* smem)
+{
+    volatile uint32_t* const flag = reinterpret_cast<volatile uint32_t*>(smem);
+    if (threadIdx.x == 0) {
+        unsigned long long* const cnt = p.progress + 3;
+        __hip_atomic_fetch_add(cnt, 1ull, HG_RLX_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        uint32_t ok = 1u;
+        while (__hip_atomic_load(cnt, HG_RLX_AGENT) < (unsigned long long)p.W + 1ull) {
+            if (__hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull || wall_clock64() - t0 > p.rdv_timeout) {
+                __hip_atomic_store(p.progress + 2, 6ull, HG_RLX_AGENT); // (the others give up at once)
+                atomicMax(&p.state->error, 6u);
+                ok = 0u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (ok && __hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull) ok = 0u; // (somebody timed out while this one was arriving)
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0u;
+    __syncthreads(); // (the word is the streaming workgroups' pair table and the walker's first array: nobody writes it before everybody has read it)
+    return ok;
+}
+
 template <int T, int DBG, int MISS>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p, const ResParams* pg)
 {
+    if (!rs_rendezvous(p, hg_smem)) return;
+    if (p.M == 0xffffffffu) return; // (a probe launch: is the grid resident at once -- hgibbs.hip, resident_probe)
     if (blockIdx.x < p.W) res_streamer<T, DBG, MISS>(p, hg_smem);
     else if (p.walker == 2) res_walker2<DBG, MISS>(*pg); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
     else res_walker<DBG, MISS>(*pg, hg_smem);

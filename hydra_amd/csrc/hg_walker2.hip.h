@@ -305,9 +305,10 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
     };
     auto pos_of_slot = [&](uint32_t s, uint32_t c) { return c + ((s - c) & bmask); };
     // inside a wait: has the sweep been given up, or is it time to give it up
+    uint32_t nspin = 0;
     auto spin_fail = [&](unsigned long long t0) {
         if (aborted()) return true;
-        if (wall_clock64() - t0 > timeout) {
+        if (wall_clock64() - t0 > timeout || ((++nspin & 1023u) == 0u && __hip_atomic_load(progress + 2, HG_RLX_AGENT) != 0ull)) { // (or the host gave the sweep up)
             if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
             return true;
         }
@@ -887,65 +888,79 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
                 continue;
             }
         }
-        // up to 64 positions from Ff on whose batch is complete (batches are in position order: a prefix)
-        const uint32_t j = Ff + (uint32_t)lane;
-        const uint32_t slot = j & bmask;
-        uint32_t bt = fb;
-        while (bt < sq && j >= sh.bl_sn[bt % W2_NB]) ++bt; // (per lane: the 64 positions may span a few batches)
-        const bool ok = j < sx && bt < done;
-        if (ok) {
-            const uint32_t rr = j % RS_RB;
-            unsigned long long w[RS_RSH], w2[RS_RSH], wp[RS_RSH][2];
-            const uint32_t np = sh.bl_np[bt % W2_NB];
-            const bool piv = np && sh.bl_p0[bt % W2_NB] < j; // a pivot in front of the column: its terms were sent
+        // up to 128 positions from Ff on whose batch is complete (batches are in position order: a prefix), two to a lane, all their loads
+        // in flight together: one round trip for a refill batch of the usual size
+        bool okv[2], pivv[2];
+        uint32_t jv[2];
+        unsigned long long w[2][RS_RSH], w2[2][RS_RSH], wp[2][RS_RSH][2];
 #pragma unroll
-            for (int s = 0; s < RS_RSH; ++s) w[s] = (uint32_t)s < rsh ? __hip_atomic_load(racc + (size_t)s * RS_RB + rr, HG_RLX_AGENT) : 0ull;
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t j = Ff + (uint32_t)(64 * h + lane);
+            jv[h] = j;
+            uint32_t bt = fb;
+            while (bt < sq && j >= sh.bl_sn[bt % W2_NB]) ++bt; // (per lane: the positions may span a few batches)
+            okv[h] = j < sx && bt < done && (h == 0 || B >= 128u); // (two positions of a pass never share a window slot)
+            const uint32_t np = sh.bl_np[bt % W2_NB];
+            pivv[h] = okv[h] && np && sh.bl_p0[bt % W2_NB] < j; // a pivot in front of the column: its terms were sent
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t rr = jv[h] % RS_RB;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) w[h][s] = (okv[h] && (uint32_t)s < rsh) ? __hip_atomic_load(racc + (size_t)s * RS_RB + rr, HG_RLX_AGENT) : 0ull;
             if constexpr (MISS) {
 #pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) w2[s] = (uint32_t)s < rsh ? __hip_atomic_load(racc2 + (size_t)s * RS_RB + rr, HG_RLX_AGENT) : 0ull;
+                for (int s = 0; s < RS_RSH; ++s) w2[h][s] = (okv[h] && (uint32_t)s < rsh) ? __hip_atomic_load(racc2 + (size_t)s * RS_RB + rr, HG_RLX_AGENT) : 0ull;
             }
-            if (piv) {
+            if (pivv[h]) {
 #pragma unroll
                 for (int s = 0; s < RS_RSH; ++s) {
                     const unsigned long long* pw = pacc + ((size_t)((uint32_t)s < rsh ? s : 0) * RS_RB + rr) * 2u;
-                    wp[s][0] = (uint32_t)s < rsh ? __hip_atomic_load(pw, HG_RLX_AGENT) : 0ull;
-                    wp[s][1] = (uint32_t)s < rsh ? __hip_atomic_load(pw + 1, HG_RLX_AGENT) : 0ull;
+                    wp[h][s][0] = (uint32_t)s < rsh ? __hip_atomic_load(pw, HG_RLX_AGENT) : 0ull;
+                    wp[h][s][1] = (uint32_t)s < rsh ? __hip_atomic_load(pw + 1, HG_RLX_AGENT) : 0ull;
                 }
-            }
-            unsigned long long now = 0ull;
-#pragma unroll
-            for (int s = 0; s < RS_RSH; ++s) now += w[s];
-            const unsigned long long tot = now - sh.rprev[rr]; // what this position's batch added (wrapping 64-bit arithmetic)
-            sh.rprev[rr] = now;
-            const double s1 = (double)(long long)tot * fx_unscale;
-            double s2 = eps_sum;
-            if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R
-                unsigned long long now2 = 0ull;
-#pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
-                const unsigned long long tot2 = now2 - sh.rprev2[rr];
-                sh.rprev2[rr] = now2;
-                s2 -= (double)(long long)tot2 * fx_unscale;
-            }
-            const uint32_t ms = j & mrmask;
-            sh.dpr[slot] = sh.mstd[ms] * (s1 - sh.mave[ms] * s2); // :1785-1790,1809
-            if (piv) {
-                unsigned long long n01 = 0ull, n23 = 0ull;
-#pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) {
-                    n01 += wp[s][0];
-                    n23 += wp[s][1];
-                }
-                const unsigned long long d01 = n01 - sh.pprev[rr], d23 = n23 - sh.pprev[RS_RB + rr];
-                sh.pprev[rr] = n01;
-                sh.pprev[RS_RB + rr] = n23;
-                sh.wpt[slot * RS_PMAX + 0] = (uint32_t)d01;
-                sh.wpt[slot * RS_PMAX + 1] = (uint32_t)(d01 >> 32);
-                sh.wpt[slot * RS_PMAX + 2] = (uint32_t)d23;
-                sh.wpt[slot * RS_PMAX + 3] = (uint32_t)(d23 >> 32);
             }
         }
-        const uint32_t n = (uint32_t)__popcll(__ballot(ok));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (okv[h]) {
+                const uint32_t j = jv[h], slot = j & bmask, rr = j % RS_RB;
+                unsigned long long now = 0ull;
+#pragma unroll
+                for (int s = 0; s < RS_RSH; ++s) now += w[h][s];
+                const unsigned long long tot = now - sh.rprev[rr]; // what this position's batch added (wrapping 64-bit arithmetic)
+                sh.rprev[rr] = now;
+                const double s1 = (double)(long long)tot * fx_unscale;
+                double s2 = eps_sum;
+                if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R
+                    unsigned long long now2 = 0ull;
+#pragma unroll
+                    for (int s = 0; s < RS_RSH; ++s) now2 += w2[h][s];
+                    const unsigned long long tot2 = now2 - sh.rprev2[rr];
+                    sh.rprev2[rr] = now2;
+                    s2 -= (double)(long long)tot2 * fx_unscale;
+                }
+                const uint32_t ms = j & mrmask;
+                sh.dpr[slot] = sh.mstd[ms] * (s1 - sh.mave[ms] * s2); // :1785-1790,1809
+                if (pivv[h]) {
+                    unsigned long long n01 = 0ull, n23 = 0ull;
+#pragma unroll
+                    for (int s = 0; s < RS_RSH; ++s) {
+                        n01 += wp[h][s][0];
+                        n23 += wp[h][s][1];
+                    }
+                    const unsigned long long d01 = n01 - sh.pprev[rr], d23 = n23 - sh.pprev[RS_RB + rr];
+                    sh.pprev[rr] = n01;
+                    sh.pprev[RS_RB + rr] = n23;
+                    sh.wpt[slot * RS_PMAX + 0] = (uint32_t)d01;
+                    sh.wpt[slot * RS_PMAX + 1] = (uint32_t)(d01 >> 32);
+                    sh.wpt[slot * RS_PMAX + 2] = (uint32_t)d23;
+                    sh.wpt[slot * RS_PMAX + 3] = (uint32_t)(d23 >> 32);
+                }
+            }
+        }
+        const uint32_t n0 = (uint32_t)__popcll(__ballot(okv[0]));
+        const uint32_t n = n0 + (n0 == (uint32_t)WAVE ? (uint32_t)__popcll(__ballot(okv[1])) : 0u);
         w2_lds_done();
         Ff += n;
         if (lane == 0) w2_st(sh.sw + S_FPUB, Ff);

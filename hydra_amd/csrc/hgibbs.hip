@@ -153,7 +153,10 @@ struct hgibbs_ctx {
     bool engine_pinned = false; // an option of the batch engine was set while engine = 0: auto means the batch engine then
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
-    int res_walker = 0;       // option walker: 0 auto, 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
+    int res_walker = 0;       // option walker: 0 auto (the second where it applies), 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
+    bool res_attr_set[8] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
+    bool res_dead = false;     // a resident kernel did not come back even after the abort word: the stream (and the handle) cannot be used any more
+    bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
@@ -1324,6 +1327,7 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     const uint32_t ntile = h->n_pad / TILE;
     uint32_t T = (ntile + (cus - 1) - 1) / (cus - 1);
     if (T > (uint32_t)RS_TMAX) return "more individuals than the compute units hold in registers (2048 each)";
+    if ((h->stride & 1023u) || (uint64_t)h->M * (h->stride >> 10) >= (1ull << 32)) return "a shard's BED columns are addressed in 32 bits of KiB";
     pl->T = (int)T;
     pl->W = (ntile + T - 1) / T;
     uint32_t B = h->window ? h->window : (uint32_t)RS_BMAX;
@@ -1331,6 +1335,56 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     pl->B = B;
     pl->ok = true;
     return nullptr;
+}
+
+// the resident kernel of a plan (T tiles per workgroup, stage clocks, missing-call build), with its LDS opt-in made on this handle's device
+static int resident_kernel(hgibbs_ctx* h, const ResPlan& pl, void (**out)(ResParams, const ResParams*))
+{
+    void (*kern)(ResParams, const ResParams*) = nullptr;
+    const bool dbg = h->debug_timing;
+    const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
+    switch (pl.T) {
+    case 1: kern = miss ? (dbg ? k_sweep_resident<1, 1, 1> : k_sweep_resident<1, 0, 1>) : (dbg ? k_sweep_resident<1, 1, 0> : k_sweep_resident<1, 0, 0>); break;
+    default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
+    }
+    const int ai = (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
+    if (!h->res_attr_set[ai]) { // (per handle: the attribute belongs to the function ON A DEVICE)
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->res_attr_set[ai] = true;
+    }
+    *out = kern;
+    return 0;
+}
+
+// Several ranks: is this rank's resident grid resident at once?  A launch of the sweep kernel that ends behind its start-of-kernel
+// rendezvous (W = the grid, M = 0 markers -- nothing else runs), then one scalar all-reduce: the ranks run the resident engine only if
+// every rank's grid is.  (One rank finds out by itself, inside the sweep's own launch: hgibbs_sweep falls back then.)  Returns non-zero
+// when some rank's grid is not resident.
+static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
+{
+    void (*kern)(ResParams, const ResParams*) = nullptr;
+    if (resident_kernel(h, pl, &kern)) return 1;
+    ResParams p{};
+    p.W = pl.W;
+    p.B = pl.B;
+    p.M = 0xffffffffu; // (probe: see k_sweep_resident)
+    p.state = h->res_state;
+    p.progress = h->res_progress;
+    p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8);
+    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), std::max(rs_walker_lds(pl.B), rs_walker2_lds(pl.B)));
+    if (hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream) != hipSuccess || hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream) != hipSuccess) return 1;
+    kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p, h->res_params);
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (hipMemcpyAsync(h->res_state_host, h->res_state, sizeof(ResState), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return 1;
+    h->scratch_host[0] = h->res_state_host->error ? 1.0 : 0.0;
+    if (hipMemcpyAsync(h->sums, h->scratch_host, sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+    if (bulk_allreduce(h, h->sums, 1, 0)) return 1;
+    if (hipMemcpyAsync(h->scratch_host, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return 1;
+    if (h->scratch_host[0] != 0.0) {
+        h->res_not_resident = true;
+        return 1;
+    }
+    return 0;
 }
 
 static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
@@ -1396,6 +1450,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         p.fx_unscale = std::ldexp(1.0, -ex);
     }
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
+    p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8); // the grid's workgroups start within microseconds of each other -- or not at all
     p.dbg = h->debug_timing ? 1 : 0;
     p.pivots = (h->nranks > 1 || h->any_missing) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
     p.nranks = h->nranks > 1 ? h->nranks : 1;
@@ -1408,7 +1463,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks)", RS_FG, HT_LDS);
         static const int env_walker = std::getenv("HGIBBS_WALKER") ? std::atoi(std::getenv("HGIBBS_WALKER")) : 0; // (test runs: the default walker of handles that do not set the option)
         const int want = h->res_walker ? h->res_walker : env_walker;
-        p.walker = (want == 2 && w2_ok) ? 2 : 1; // (auto: the first walker -- the second is not faster yet)
+        p.walker = (want != 1 && w2_ok) ? 2 : 1; // (auto: the second walker where it applies) // (auto: the first walker -- the second is not faster yet)
     }
     p.pred = h->pred;
     p.tune = h->res_tune;
@@ -1430,18 +1485,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
     const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), p.walker == 2 ? rs_walker2_lds(pl.B) : rs_walker_lds(pl.B));
     void (*kern)(ResParams, const ResParams*) = nullptr;
-    const bool dbg = h->debug_timing;
-    const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
-    switch (pl.T) {
-    case 1: kern = miss ? (dbg ? k_sweep_resident<1, 1, 1> : k_sweep_resident<1, 0, 1>) : (dbg ? k_sweep_resident<1, 1, 0> : k_sweep_resident<1, 0, 0>); break;
-    default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
-    }
-    static bool attr_set[8] = {};
-    const int ai = (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
-    if (!attr_set[ai]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[ai] = true;
-    }
+    if (resident_kernel(h, pl, &kern)) return 1;
     {
         // every workgroup of the grid waits for the others: all of them must be resident at once
         int per_cu = 0;
@@ -1463,27 +1507,59 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     {
         // the kernel bounds every wait of its own; the host's deadline is the last line of defence (a kernel that does not come
         // back is reported with where its walker and its first streaming workgroup stand, not waited for)
-        const auto t_start = std::chrono::steady_clock::now();
-        const double limit_s = h->res_deadline_s > 0.0 ? h->res_deadline_s : 30.0 + 20.0 * h->res_timeout_s + 1e-6 * (double)h->M;
+        // A healthy sweep keeps moving: the deadline counts from the walker's last sign of life (its round counter, fetched on a second
+        // stream once a second), not from the launch -- a dense model on a throttled device may legitimately take minutes.
+        auto t_start = std::chrono::steady_clock::now();
+        auto t_probe = t_start;
+        unsigned long long last_round = ~0ull;
+        const double limit_s = h->res_deadline_s > 0.0 ? h->res_deadline_s : 30.0 + 20.0 * h->res_timeout_s;
         for (;;) {
             const hipError_t q = hipStreamQuery(h->stream);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return fail("hgibbs_sweep: resident engine: %s", hipGetErrorString(q));
-            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-            if (el > limit_s)
-            {
-                for (int i = 0; i < 16; ++i) h->res_progress_host[i] = 0;
-                if (hipMemcpyAsync(h->res_progress_host, h->res_progress, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->aux_stream) == hipSuccess)
-                    (void)hipStreamSynchronize(h->aux_stream);
+            const auto now = std::chrono::steady_clock::now();
+            const double el = std::chrono::duration<double>(now - t_start).count();
+            if (std::chrono::duration<double>(now - t_probe).count() > std::min(1.0, 0.25 * limit_s)) {
+                t_probe = now;
+                if (hipMemcpyAsync(h->res_progress_host, h->res_progress, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->aux_stream) == hipSuccess &&
+                    hipStreamSynchronize(h->aux_stream) == hipSuccess && (h->res_progress_host[0] >> 8) != last_round) {
+                    last_round = h->res_progress_host[0] >> 8;
+                    t_start = now; // the walker has moved on
+                    continue;
+                }
+            }
+            if (el > limit_s) {
+                // no progress for limit_s: tell the kernel to give up (its workgroups poll the word wherever they wait), give it the time its own
+                // bounded waits need, and report where it stood; a kernel that does not even do that has taken the stream with it
                 const unsigned long long* pr = h->res_progress_host;
-                return fail("hgibbs_sweep: the resident kernel has not come back after %.0f s: walker at round %llu stage %llu, streaming workgroup 0 at message %llu stage %llu", el,
-                            (unsigned long long)(pr[0] >> 8), (unsigned long long)(pr[0] & 255u), (unsigned long long)(pr[1] >> 8), (unsigned long long)(pr[1] & 255u));
+                const unsigned long long w0 = pr[0], w1 = pr[1];
+                h->res_progress_host[8] = 3ull;
+                (void)hipMemcpyAsync(h->res_progress + 2, h->res_progress_host + 8, sizeof(unsigned long long), hipMemcpyHostToDevice, h->aux_stream);
+                (void)hipStreamSynchronize(h->aux_stream);
+                const auto t_abort = std::chrono::steady_clock::now();
+                bool back = false;
+                while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_abort).count() < 5.0 + 3.0 * h->res_timeout_s) {
+                    if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+                        back = true;
+                        break;
+                    }
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                }
+                if (!back) h->res_dead = true;
+                return fail("hgibbs_sweep: the resident kernel made no progress for %.0f s: walker at round %llu stage %llu, streaming workgroup 0 at message %llu stage %llu; it was told to stop and %s", el,
+                            (unsigned long long)(w0 >> 8), (unsigned long long)(w0 & 255u), (unsigned long long)(w1 >> 8), (unsigned long long)(w1 & 255u),
+                            back ? "did (the sweep's results are void)" : "did NOT come back: this handle cannot be used any more");
             }
             if (el > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.5 ? 2000 : 50));
         }
     }
     const auto t_kernel = std::chrono::steady_clock::now();
     const ResState& st = *h->res_state_host;
+    if (st.error == 6u) { // the grid was only partly resident (another process or stream on the device): nothing has been touched
+        h->res_not_resident = true;
+        fail("hgibbs_sweep: the resident grid of %u workgroups was not resident at once (the device is shared)", pl.W + 1);
+        return 2;
+    }
     if (st.error)
         return fail("hgibbs_sweep: resident engine abort code %u at cursor %u (2 = rng staging overrun, 3 = a workgroup timed out, 5 = raw dot outside the fixed-point range)", st.error, st.cursor);
     if (st.cursor != h->M) return fail("hgibbs_sweep: resident engine stopped at cursor %u of %u", st.cursor, h->M);
@@ -1533,6 +1609,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
                  const uint8_t* adaV_host, hgibbs_rng_state* rng, int32_t* cass_host, uint64_t* nnz_updates)
 {
     if (!h || !h->bed) return fail("hgibbs_sweep: no data loaded");
+    if (h->res_dead) return fail("hgibbs_sweep: a resident kernel of this handle never came back: the handle cannot be used any more");
     if (h->G < 1) return fail("hgibbs_sweep: model not set");
     if (!order_host || !sigmaG_host || !estPi_host || !adaV_host || !rng) return fail("hgibbs_sweep: null argument");
     const auto t_prep0 = std::chrono::steady_clock::now();
@@ -1598,6 +1675,10 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
     {
         const char* why = resident_plan(h, &plan);
         if (h->engine == 1 || (h->engine == 0 && h->engine_pinned)) plan.ok = false;
+        if (h->engine == 0 && h->res_not_resident && plan.ok) {
+            plan.ok = false;
+            why = "an earlier resident grid was not resident at once (the device is shared)";
+        }
         if (h->nranks > 1) {
             // the ranks run ONE engine: the resident one only if every rank can (a rank with a larger shard, another option or no
             // mailbox would otherwise wait for peers that are in the other engine's exchange)
@@ -1610,6 +1691,11 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
                 if (plan.ok) why = "another rank cannot run it";
                 plan.ok = false;
             }
+            // (every rank has the same answer now) a rank whose grid is not resident at once must be known BEFORE its peers wait for it
+            if (plan.ok && resident_probe(h, plan)) {
+                plan.ok = false;
+                why = "some rank's resident grid is not resident at once (a shared device)";
+            }
         }
         if (h->engine == 2 && !plan.ok) return fail("hgibbs_sweep: the resident engine does not apply: %s", why ? why : "the batch engine was asked for by an option");
         if (std::getenv("HGIBBS_DEBUG"))
@@ -1619,7 +1705,13 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
         std::fprintf(stderr, "[hgibbs] sweep preparation (checks, tables, order / adaV upload, metadata gather) %.3f ms\n",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
     h->res_all_ada = std::memchr(adaV_host, 0, (size_t)M) == nullptr;
-    if (plan.ok) return sweep_resident(h, plan, sigmaE, rng, cass_host, nnz_updates);
+    if (plan.ok) {
+        const int rc = sweep_resident(h, plan, sigmaE, rng, cass_host, nnz_updates);
+        // 2: the grid was found partly resident at the kernel's start (a shared device) and NOTHING was touched: with engine = 0 this sweep and
+        // the following ones run on the batch engine (several ranks have agreed on that before the launch: resident_probe)
+        if (rc != 2 || h->engine == 2 || h->nranks > 1) return rc ? 1 : 0;
+        if (std::getenv("HGIBBS_DEBUG")) std::fprintf(stderr, "[hgibbs] engine: the resident grid was not resident at once -- this sweep and the following ones run on the batch engine\n");
+    }
 
     SweepParams p{};
     p.bed = h->bed;

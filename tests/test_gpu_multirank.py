@@ -249,3 +249,68 @@ def test_bench_two_ranks_under_the_launcher():
     assert d["config"]["N"] == 40000 and d["config"]["M"] == 4000
     assert d["config"]["exchange"] in ("p2p-mailbox", "gloo-allreduce (host)") and d["config"]["bulk_reductions"] == "gloo"
     assert "roofline" in d and d["roofline"]["bound"] in ("latency", "hbm") and "cpu_baseline" in d
+
+
+# ---------------------------------------------------------------------------
+# a device that is not ours alone: two INDEPENDENT processes (not ranks of one job), each with a shard whose resident grid
+# needs more than half of the compute units, default options
+# ---------------------------------------------------------------------------
+def _lone_worker(idx, bed, y, N, iters, barrier, q):
+    import time
+    from hydra_amd import capi
+    try:
+        dev = capi.Device(0)
+        dev.load_bed(bed, N)
+        ch = capi.Chain(dev, y, seed=1222, shuffle=1)
+        engines, times, comps, betas = [], [], [], []
+        for _ in range(iters):
+            barrier.wait(timeout=120)  # both processes start their sweeps together
+            t0 = time.perf_counter()
+            ch.iterate()
+            times.append(time.perf_counter() - t0)
+            engines.append(dev.sweep_stats()["engine"])
+            beta, comp, _ = dev.get_beta()
+            comps.append(comp.copy())
+            betas.append(beta.copy())
+        q.put((idx, engines, times, comps, betas))
+    except Exception as e:
+        q.put((idx, repr(e)))
+
+
+def test_two_processes_share_the_device_with_default_options(oracle):
+    """The resident grid is a set of workgroups that wait for each other: all of them must be resident at once, and the host's
+    occupancy check cannot see another process.  Two processes on one GPU, each with 140 001 individuals (137 streaming
+    workgroups + the walker: more than half of the 256 compute units), default engine: whichever engine each sweep ends up on
+    -- the kernel's start-of-kernel rendezvous finds a partly resident grid within 0.1 s, touches nothing, and the library runs
+    that sweep and the following ones on the batch engine -- both walk the oracle's chain, and no sweep stalls for seconds."""
+    import torch.multiprocessing as mp
+    import orc
+    from hydra_amd import synth
+    M, N, iters = 200, 140001, 4
+    geno = synth.make_genotypes(M, N, seed=71, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=72, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+    ref = orc.Chain(oracle, bed, N, y, seed=1222, shuffle=1)
+    want = []
+    for _ in range(iters):
+        ref.iterate()
+        want.append((ref.arr("components").copy(), ref.arr("beta").copy()))
+    ctx = mp.get_context("spawn")
+    q, barrier = ctx.Queue(), ctx.Barrier(2)
+    procs = [ctx.Process(target=_lone_worker, args=(i, bed, y, N, iters, barrier, q)) for i in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert len(r) == 5, "process %s failed: %s" % (r[0], r[1])
+        idx, engines, times, comps, betas = r
+        assert set(engines) <= {1, 2}
+        assert max(times) < 1.5, "a sweep stalled: %s (engines %s)" % (times, engines)
+        for it in range(iters):
+            assert np.array_equal(comps[it], want[it][0]), "process %d diverged from the oracle at iteration %d (engines %s)" % (idx, it, engines)
+            assert np.all(np.abs(betas[it] - want[it][1]) <= 1e-9 * np.maximum(1.0, np.abs(want[it][1])))
+        # once a grid was found partly resident the handle stays on the batch engine
+        if 1 in engines:
+            assert engines[engines.index(1):] == [1] * (iters - engines.index(1))

@@ -150,6 +150,27 @@ def test_grouped_mixture_multi_tile_vs_oracle(oracle, engine):
     _run_vs_oracle(oracle, bed, y, N, {"engine": engine}, iters=3, mS=mS, groups=groups)
 
 
+@pytest.mark.parametrize("walker", [1, 2])
+@pytest.mark.parametrize("miss_cols", [0.0, 0.25])
+def test_resident_two_tiles_64_workgroups_vs_oracle(oracle, miss_cols, walker):
+    """The geometry the headline runs -- two wave tiles per streaming workgroup, many workgroups -- against the ORACLE: 130 001
+    individuals on 65 compute units (64 streaming workgroups of 2 048 individuals + the walker), clean and with 2 % missing calls
+    in a quarter of the columns (the missing-call build next to clean columns), by both walkers."""
+    M, N = 400, 130001
+    bed, y = _case(M, N, miss_cols, seed=11)
+    dev_opts = {"engine": 2, "res_cus": 65, "walker": walker}
+    _run_vs_oracle(oracle, bed, y, N, dev_opts, iters=3)
+    d = capi.Device(0)
+    d.load_bed(bed, N)
+    for k, v in dev_opts.items():
+        d.set_option(k, v)
+    ch = capi.Chain(d, y, seed=31, shuffle=1)
+    ch.iterate()
+    ss = d.sweep_stats()
+    assert ss["engine"] == 2 and ss["tiles_per_workgroup_max"] == 2 and ss["walker"] == walker
+    d.close()
+
+
 # ---------------------------------------------------------------------------
 # sharded: two processes on one GPU, more than 49 152 individuals per rank (several tile groups per workgroup on
 # every rank), each replica against the oracle

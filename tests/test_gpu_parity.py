@@ -544,7 +544,7 @@ def test_full_size_properties_c2():
         assert close(res[0][3]["sigmaE"], r[3]["sigmaE"])
 
 
-@pytest.mark.parametrize("cfg", ["c3", "c4"])
+@pytest.mark.parametrize("cfg", ["c3", "c4", "c4-missing"])
 def test_full_size_properties_c3_c4(cfg):
     """BASELINE configs 3 (N=200 000, M=500 000, two groups) and 4 (N=500 000, M=1 000 000: 125 GB of packed
     genotypes in HBM) at full size through the same size-independent properties: counts add up, the residual
@@ -552,6 +552,7 @@ def test_full_size_properties_c3_c4(cfg):
     the sweep -- the resident engine (the default at these shapes), the batch engine with Gram corrections, and the batch
     engine's plain path (gram = 0, another batch width) -- walk the same chain."""
     N, M, G = (200000, 500000, 2) if cfg == "c3" else (500000, 1000000, 1)
+    missing = 0.01 if cfg == "c4-missing" else 0.0  # (1 % missing calls in every column: the resident MISS build at 245 workgroups against the batch engine's)
     groups = None if G == 1 else (np.arange(M) % 2).astype(np.int32)
     mS = np.array([[0.0, 0.0001, 0.001, 0.01]]) if G == 1 else np.array([[0.0, 0.001, 0.01, 0.1]] * 2)
     res = []
@@ -560,7 +561,7 @@ def test_full_size_properties_c3_c4(cfg):
         if batch:  # naming a batch width pins the batch engine; without options the library picks the resident engine here
             dev.set_option("batch", batch)
             dev.set_option("gram", gram)
-        dev.synth_bed(N, M, seed=42)
+        dev.synth_bed(N, M, seed=42, missing_rate=missing)
         rng = np.random.default_rng(1)
         dev.set_residual(rng.normal(size=N))
         for j, b in zip(rng.choice(M, 300, replace=False), rng.normal(0, 0.04, 300)):

@@ -54,7 +54,7 @@ __global__ void k(unsigned long long* out, double* sink, int iters, const double
         }
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = c1 - c0;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicMax(out, c1 - c0); // the SLOWEST wave of the workgroup (the older wave of a SIMD is served first)
     sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 template <int V>
@@ -70,6 +70,7 @@ void run(const char* name, int per_block)
         const int threads = 256 * wps, iters = 200;
         k<V><<<256, threads>>>(out, sink, iters, ein);
         hipDeviceSynchronize();
+        hipMemset(out, 0, 8);
         k<V><<<256, threads>>>(out, sink, iters, ein);
         hipDeviceSynchronize();
         unsigned long long c;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, double* sink, 
     } else
         cols(std::integral_constant<int, 8>{});
     unsigned long long c1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = c1 - c0;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicMax(out, c1 - c0); // the SLOWEST wave of the workgroup (the older wave of a SIMD is served first)
     if (MODE & 32)
         for (int i = 0; i < 80; ++i) tot += pad[i];
     sink[blockIdx.x * blockDim.x + threadIdx.x] = tot;
@@ -111,6 +111,7 @@ template <int MODE, int UNR>
 void run(const char* name, const uint8_t* bed, size_t stride, const int* order, int ncol, const double* ein, unsigned long long* out, double* sink)
 {
     for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(out, 0, 8);
         k<MODE, UNR><<<245, 512, 160 * 1024>>>(out, sink, bed, stride, order, ncol, ein);
         hipDeviceSynchronize();
     }

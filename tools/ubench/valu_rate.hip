@@ -28,7 +28,7 @@ __global__ void k(unsigned long long* out, double* sink, int iters)
         }
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = c1 - c0;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicMax(out, c1 - c0); // the SLOWEST wave of the workgroup (the older wave of a SIMD is served first)
     sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + w0 + w1 + w2 + w3 + t0 + t1 + t2 + t3;
 }
 template <int OP>
@@ -42,6 +42,7 @@ void run(const char* name)
         const int threads = 256 * waves_per_simd, iters = 200;
         k<OP><<<256, threads>>>(out, sink, iters);
         hipDeviceSynchronize();
+        hipMemset(out, 0, 8);
         k<OP><<<256, threads>>>(out, sink, iters);
         hipDeviceSynchronize();
         unsigned long long c;
