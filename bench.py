@@ -55,17 +55,23 @@ def algorithmic_bytes_bw(n, M, nnz, nshift):
     return M * (col + 8 * n) + nnz * 24 * n
 
 
-def committed_profile(kind, N, M, world, kernel="k_sweep_batch"):
+def valu_floor_ms(n, M, clock_hz=2.4e9, simds=1024):
+    """The least time one sweep's arithmetic can take on this design: three vector instructions per genotype-lane (extract, convert,
+    multiply-add), one instruction per SIMD per four clocks."""
+    return 3.0 * n * M / 64.0 * 4.0 / simds / clock_hz * 1e3
+
+
+def committed_profile(kind, N, M, world, kernel="k_sweep_batch", missing=0.0):
     """A PMC summary committed under profiles/ (tools/profile_round.sh), newest round first, IF it was taken on this very
     workload (same N and M, one GPU); (dict, "file: command") or (None, None).  bench.py never presents such a figure
     without its source: the counters need rocprofv3 passes of their own and cannot be read inside this run."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc_%s.json" % kind)), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % kind)), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("N") == N and d.get("M") == M and world == 1 and d.get("kernel", "k_sweep_batch") == kernel:
+        if d.get("N") == N and d.get("M") == M and world == 1 and d.get("kernel", "k_sweep_batch") == kernel and float(d.get("missing_rate", 0.0)) == float(missing):
             return d, "%s: %s" % (os.path.relpath(f, ROOT), d.get("command", ""))
     return None, None
 
@@ -585,8 +591,8 @@ def main():
         kernel_ms_avg = sweep_ms / max(1, launches)
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
         kname = "k_sweep_resident" if resident else "k_sweep_batch"
-        traffic, traffic_src = committed_profile("traffic", N, M, world, kname)
-        valu, valu_src = committed_profile("valu", N, M, world, kname)
+        traffic, traffic_src = committed_profile("traffic", N, M, world, kname, args.missing)
+        valu, valu_src = committed_profile("valu", N, M, world, kname, args.missing)
         anatomy = anatomy_all  # measured by every rank together (below the timed region), reported by rank 0
         col_bytes = (n_local + 3) // 4
         # bytes that MUST cross the HBM boundary per sweep: every column once; the batch engine also reads and writes eps once per update
@@ -604,6 +610,11 @@ def main():
                 "hbm_frac_measured": (traffic["traffic_bytes_per_launch"] / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "valu_issue_frac_whole_launch": valu["valu_issue_frac"] if valu else None,
                 "valu_source": valu_src,
+                # what bounds the design: every genotype is decoded and multiplied -- field extract, int -> f64, fused multiply-add: three
+                # wave-instructions per 64 genotypes at least, and a SIMD issues ONE vector instruction per four clocks however many waves it
+                # holds (tools/ubench/valu_rate.hip measures 4.2-4.4): N x M x 3 / 64 x 4 clocks over the chip's 1024 SIMDs
+                "valu_floor_ms": valu_floor_ms(n_local, M),
+                "frac_of_valu_floor": valu_floor_ms(n_local, M) / (sweep_ms / K) if sweep_ms > 0 else None,
                 "working_launches_per_iter": launches / K, "enqueued_launches_per_iter": enqueued / K,
                 "accepted_per_launch": accepted / max(1, launches),
                 "columns_streamed_per_accepted": streamed / max(1, accepted),
@@ -665,6 +676,9 @@ def main():
                        "carried_columns_per_iter": carried / K, "causal_frac": args.causal_frac,
                        "tiles_per_workgroup": [min(s["tiles_per_workgroup_min"] for s, _ in stats), max(s["tiles_per_workgroup_max"] for s, _ in stats)],
                        "setup_s": t_setup,
+                       **({"multi_gpu_note": "no scaling curve has been measured on hardware (the pool gives one GPU); DESIGN.md section 5: the chain's "
+                                             "round is latency, not streaming -- sharding the individuals buys capacity (shards of 522 K individuals per GPU), "
+                                             "predicted 0.9-1.0x at 2-8 GPUs"} if world > 1 else {}),
                        **({"missing_rate": args.missing} if args.missing else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": roof,
         }

@@ -190,17 +190,17 @@ __device__ __forceinline__ u4_t rs_u4(uint32_t x, uint32_t y, uint32_t z, uint32
 }
 
 __host__ __device__ constexpr size_t rs_streamer_lds(uint32_t B, int T) { return 512 + (size_t)B * 97 + (size_t)B * 256 * T; }
-// build MISS: a copy of the workgroup's eps slice in LDS, addressable by individual ([(16 t + slot) * 64 + lane] doubles), for the sums
-// over a column's (few) missing calls.  The build keeps two group sums per refilled position instead of eight and no pivot terms: the
-// copy lives in what that frees of the plain layout (between 512 + 32 B and the ring) when it fits there, else behind the ring.
-__host__ __device__ constexpr size_t rs_epsl_off(uint32_t B, int T) { return ((size_t)B * 65 >= (size_t)8192 * T) ? 512 + (size_t)B * 32 : rs_streamer_lds(B, T); }
-__host__ __device__ constexpr size_t rs_streamer_lds_miss(uint32_t B, int T)
-{
-    return rs_streamer_lds(B, T) > rs_epsl_off(B, T) + (size_t)8192 * T ? rs_streamer_lds(B, T) : rs_epsl_off(B, T) + (size_t)8192 * T;
-}
+// build MISS: a layout of its own in front of the ring -- (mave, mstd) of the window slots (16 B each), this round's refill: four
+// 16-lane partial sums of s1 per position (32 B) and one 8-byte INTEGER accumulator of R = sum of eps over the column's missing calls
+// (fixed point: the lanes add their parts with LDS atomics -- integers, so the order does not matter), and a copy of the workgroup's eps
+// slice addressable by individual ([(16 t + slot) * 64 + lane] doubles) for the gather over a column's (few) missing calls.
+__host__ __device__ constexpr size_t rs_miss_part_off(uint32_t B) { return 512 + (size_t)B * 16; }
+__host__ __device__ constexpr size_t rs_miss_racc_off(uint32_t B) { return 512 + (size_t)B * 48; }
+__host__ __device__ constexpr size_t rs_epsl_off(uint32_t B, int T) { return 512 + (size_t)B * 56; }
+__host__ __device__ constexpr size_t rs_miss_ring_off(uint32_t B, int T) { return rs_epsl_off(B, T) + (size_t)8192 * T; }
+__host__ __device__ constexpr size_t rs_streamer_lds_miss(uint32_t B, int T) { return rs_miss_ring_off(B, T) + (size_t)B * 256 * T; }
 static_assert(rs_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds_miss(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds_miss(RS_BMAX, 1) <= 160 * 1024,
               "the largest window at the most tiles per workgroup fits the 160 KB of LDS of a compute unit, in both builds");
-static_assert(rs_epsl_off(RS_BMAX, RS_TMAX) + (size_t)8192 * RS_TMAX <= 512 + (size_t)RS_BMAX * 97, "there, the LDS copy of eps ends in front of the ring");
 
 // ---------------------------------------------------------------------------------------------------------------
 // streaming workgroup
@@ -424,8 +424,9 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     double2* const tab = reinterpret_cast<double2*>(smem);                        // pair table of the event's addends (256 B)
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
     double2* const meta = reinterpret_cast<double2*>(smem + 512);                 // (mave, mstd) of the window slots
-    double* const part = reinterpret_cast<double*>(smem + 512 + (size_t)B * 16);       // this round's refill: [position - Sx][8] sums of the wave's eight-lane groups
-    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + 512 + (size_t)B * 97);  // [B][64 * T] codes of the window columns
+    double* const part = reinterpret_cast<double*>(smem + 512 + (size_t)B * 16);       // this round's refill: [position - Sx][8] sums of the wave's eight-lane groups (build MISS: [.][4] sums of its 16-lane rows)
+    unsigned long long* const rlds = reinterpret_cast<unsigned long long*>(smem + rs_miss_racc_off(B)); // build MISS: [position - Sx] fixed-point sum of eps over the column's missing calls
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + (MISS ? rs_miss_ring_off(B, T) : 512 + (size_t)B * 97)); // [B][64 * T] codes of the window columns
     double* const epsl = reinterpret_cast<double*>(smem + rs_epsl_off(B, T));           // build MISS: the eps slice by individual (see rs_epsl_off)
     const bool timing = DBG && wg == 0 && tid == 0;
     unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(smem + 384); // [8] stage clocks of the debug build (in LDS: sixteen registers less)
@@ -467,7 +468,10 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         }
     };
     eps_to_lds();
-    if constexpr (MISS) __syncthreads();
+    if constexpr (MISS) {
+        for (uint32_t i = (uint32_t)tid; i < B; i += RS_BLOCK) rlds[i] = 0ull;
+        __syncthreads();
+    }
     uint32_t C = 0, Sx = 0, seq = 0, nev = 0;
     uint32_t pcur = 0; // index into p.pred of the first predicted position at or behind the cursor
     const rs_cu32* const pred4 = (const rs_cu32*)p.pred; // (constant address space: uniform indices make scalar loads)
@@ -657,7 +661,6 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 const uint32_t kr = nk + (((uint32_t)r - nk) & (uint32_t)(RS_PF - 1));
                 if (kr - nk < m) { // wave-uniform
                     double a[4];
-                    if constexpr (MISS) a[0] = a[1] = a[2] = a[3] = 0.0;
                     uint32_t gw[T];
                     rs_set_read<T, r>(gw, keep);
                     const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_of(kr));
@@ -670,41 +673,48 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                         for (int t = 0; t < T; ++t) rp[t] = gram_xform(gw[t]);
                     }
                     if constexpr (MISS) {
-                        // a column with missing calls (:1785-1790): s1 over the calls that are there -- the missing ones' fields are cleared,
-                        // weight 0 -- and R = sum of eps over the missing ones (s2 = sum of eps - R), the same three instructions per
-                        // individual on the 1-bit field; both summed over the whole wave here (the LDS that would hold eight partial sums
-                        // of each is the window's)
-                        double rsum = 0.0;
+                        // a column with missing calls (:1785-1790).  The device code of a missing call is 11: its field would weigh 3.  Instead of
+                        // clearing the fields (five instructions a dword, on the VALU that bounds this loop) the dot is taken as it stands,
+                        // s1' = s1 + 3 R with R = sum of eps over the missing calls -- which s2 = sum of eps - R needs anyway -- and the walker
+                        // takes 3 R off again, in integers (both travel as fixed point).  R in the reference's index-list form
+                        // (src/BayesRRm.cpp:331-341): a gather over the ~1 % of individuals whose call is missing, from the LDS copy of eps.
                         if (__builtin_amdgcn_readlane(gal, r) & 0x20000000) { // wave-uniform
-                            unsigned long long mall = 0ull; // the lane's missing calls of all its dwords: bit 32 t + 2 s
+                            uint32_t mall = 0u; // the lane's missing calls of its dwords in ONE word: a dword's are at the even bits, tile t's shifted by t
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                const uint32_t mm = gw[t] & (gw[t] >> 1) & 0x55555555u;
-                                const uint32_t clean = gw[t] & ~(mm | (mm << 1));
-                                fma_col(clean, e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
-                                rp[t] = gram_xform(clean) | (mm << 1);
-                                mall |= (unsigned long long)mm << (32 * t);
+                                const uint32_t hi = (gw[t] >> 1) & 0x55555555u, mm = gw[t] & hi;
+                                rp[t] = (gw[t] | hi) ^ mm; // the x form 00 / 01 / 11, a missing call the free code 10
+                                mall |= mm << t;
                             }
-                            // the few missing calls of the lane, one by one (the reference's index-list form, src/BayesRRm.cpp:331-341:
-                            // a gather over ~1 % of the individuals): eps by individual comes from the LDS copy ([(16 t + s) * 64 + lane])
-                            while (mall) { // per lane; the wave goes round as often as its fullest lane needs
-                                const uint32_t b = (uint32_t)__ffsll((long long)mall) - 1u;
-                                rsum += epsl[(b >> 1) * 64u + (uint32_t)lane];
-                                mall &= mall - 1ull;
+                            fma_dword<true>(gw[0], e[0], a[0], a[1], a[2], a[3]);
+                            if constexpr (T == 2) fma_dword<false>(gw[T - 1], e[T - 1], a[0], a[1], a[2], a[3]);
+                            if (mall) { // (per lane: about a quarter of the lanes at 1 % missing calls)
+                                double rsum = 0.0;
+                                do { // the wave goes round as often as its fullest lane needs; bit b = slot b >> 1 of tile b & 1: eps at [(16 t + s) * 64 + lane]
+                                    const uint32_t b = (uint32_t)__builtin_ctz(mall);
+                                    rsum += epsl[(((b & 1u) << 4) | (b >> 1)) * 64u + (uint32_t)lane];
+                                    mall &= mall - 1u;
+                                } while (mall);
+                                const double MAGIC = 6755399441055744.0; // the lane's part as a fixed-point integer: x + 1.5 2^52 rounds to nearest
+                                const double xr = fmin(fmax(rsum * p.fx_scale, -2.2e15), 2.2e15); // (a part beyond the range is held at it: the finishing thread refuses the sum)
+                                // (an instruction of its own per lane -- the LDS serialises the few lanes that meet at the address; the compiler's form of the
+                                // atomic is a scalar loop over the active lanes first, ten instructions a lane)
+                                const unsigned long long fr = (unsigned long long)(__double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC));
+                                asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(rlds + (pos - Sx))), "v"(fr) : "memory");
                             }
                         } else {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) {
-                                fma_col(gw[t], e[t], a[0], a[1], a[2], a[3], std::make_integer_sequence<int, IPT / 4>{});
-                                rp[t] = gram_xform(gw[t]);
-                            }
+                            for (int t = 0; t < T; ++t) rp[t] = gram_xform(gw[t]);
+                            fma_dword<true>(gw[0], e[0], a[0], a[1], a[2], a[3]);
+                            if constexpr (T == 2) fma_dword<false>(gw[T - 1], e[T - 1], a[0], a[1], a[2], a[3]);
                         }
-                        const double v = rs_wave_sum_f64((a[0] + a[1]) + (a[2] + a[3]));
-                        const double w = rs_wave_sum_f64(rsum);
-                        if (lane == 63) {
-                            part[(pos - Sx) * 2u] = v;
-                            part[(pos - Sx) * 2u + 1u] = w;
-                        }
+                        // the lane sums meet in the wave's four 16-lane rows (four DPP steps, fixed order); one thread per column adds the four
+                        double v = (a[0] + a[1]) + (a[2] + a[3]);
+                        v += rs_dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+                        v += rs_dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+                        v += rs_dpp_f64<0x141>(v); // row_half_mirror
+                        v += rs_dpp_f64<0x140>(v); // row_mirror
+                        if ((lane & 15) == 0) part[(pos - Sx) * 4u + ((uint32_t)lane >> 4)] = v;
                     } else {
                     fma_dword<true>(gw[0], e[0], a[0], a[1], a[2], a[3]);
                     if constexpr (T == 2) fma_dword<false>(gw[T - 1], e[T - 1], a[0], a[1], a[2], a[3]);
@@ -812,11 +822,12 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             const double MAGIC = 6755399441055744.0;
             double s1;
             if constexpr (MISS) {
-                s1 = part[t * 2u];
-                const double xr = part[t * 2u + 1u] * p.fx_scale;
-                if (!(fabs(xr) < 2.2e15)) atomicMax(&p.state->error, 5u);
-                const long long fr = __double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC);
-                __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr, HG_RLX_AGENT);
+                const double* pp = part + t * 4u;
+                s1 = ((pp[0] + pp[1]) + pp[2]) + pp[3]; // (with weight 3 on the missing calls: the walker takes 3 R off, in integers)
+                const unsigned long long fr = rlds[t];
+                rlds[t] = 0ull; // (the next round's lanes add behind this round's last barrier)
+                if (!(fabs((double)(long long)fr) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range: the sweep is refused, not wrapped
+                if (fr) __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), fr, HG_RLX_AGENT);
             } else {
                 const double* pp = part + t * 8u;
                 s1 = pp[0];
@@ -1202,9 +1213,10 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             tot = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic)
             sh.rprev[j % RS_RB] = now;
         }
-        const double s1 = (double)(long long)tot * p.fx_unscale;
+        double s1 = (double)(long long)tot * p.fx_unscale;
         double s2 = p.eps_sum;
         if (MISS && p.nranks > 1) {
+            s1 = (double)(long long)(tot - 3ull * totR) * p.fx_unscale; // (the streamed dot weighs a missing call 3: s1' = s1 + 3 R, exact integers)
             s2 -= (double)(long long)totR * p.fx_unscale;
         } else if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R
             unsigned long long* base2 = p.racc2 + (j % RS_RB);
@@ -1216,6 +1228,7 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
             const unsigned long long tot2 = now2 - sh.rprev2[j % RS_RB];
             sh.rprev2[j % RS_RB] = now2;
+            s1 = (double)(long long)(tot - 3ull * tot2) * p.fx_unscale; // (the streamed dot weighs a missing call 3: s1' = s1 + 3 R, exact integers)
             s2 -= (double)(long long)tot2 * p.fx_unscale;
         }
         sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * s2);

@@ -930,14 +930,15 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
                 for (int s = 0; s < RS_RSH; ++s) now += w[h][s];
                 const unsigned long long tot = now - sh.rprev[rr]; // what this position's batch added (wrapping 64-bit arithmetic)
                 sh.rprev[rr] = now;
-                const double s1 = (double)(long long)tot * fx_unscale;
+                double s1 = (double)(long long)tot * fx_unscale;
                 double s2 = eps_sum;
-                if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R
+                if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R; the streamed dot weighs a missing call 3: s1' = s1 + 3 R
                     unsigned long long now2 = 0ull;
 #pragma unroll
                     for (int s = 0; s < RS_RSH; ++s) now2 += w2[h][s];
                     const unsigned long long tot2 = now2 - sh.rprev2[rr];
                     sh.rprev2[rr] = now2;
+                    s1 = (double)(long long)(tot - 3ull * tot2) * fx_unscale; // (exact: integers)
                     s2 -= (double)(long long)tot2 * fx_unscale;
                 }
                 const uint32_t ms = j & mrmask;

@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Fold the PMC pass summaries of tools/profile_round.sh into the two JSON files bench.py quotes (with their source):
-  <R>_c4_pmc_traffic.json   memory-side bytes per working launch of k_sweep_batch over the TIMED iterations
+  <R>_<tag>_pmc_traffic.json   memory-side bytes per working launch of k_sweep_batch over the TIMED iterations
                             (FETCH_SIZE doubled -- the gfx950 correction of MI355X_MICROARCH.md, HBM section -- plus
                             WRITE_SIZE; both counters are in KiB)
-  <R>_c4_pmc_valu.json      SQ / GRBM counters of the same launches: VALU issue share, wave occupancy, wait shares
-usage: pmc_fold.py <dir with the pass outputs> <round tag>"""
+  <R>_<tag>_pmc_valu.json    SQ / GRBM counters of the same launches: VALU issue share, wave occupancy, wait shares
+usage: pmc_fold.py <dir with the pass outputs> <round tag> [workload tag, default c4]"""
 import json
 import os
 import sys
 
 O, R = sys.argv[1], sys.argv[2]
+TAG = sys.argv[3] if len(sys.argv) > 3 else "c4"
 
 
 def last_json(path):
@@ -22,7 +23,7 @@ def bench_of(name):
 
 
 def work(name, ctr):
-    return last_json(os.path.join(O, "%s_c4_pmc_%s.txt" % (R, name)))[ctr]
+    return last_json(os.path.join(O, "%s_%s_pmc_%s.txt" % (R, TAG, name)))[ctr]
 
 
 b = bench_of("FETCH_SIZE")
@@ -33,7 +34,7 @@ traffic = (2.0 * f["mean_work"] + w["mean_work"]) * 1024.0
 json.dump({
     "command": cmd + " (FETCH_SIZE and WRITE_SIZE in separate passes, counters only); dispatches of the timed iterations only "
                "(the last launches_per_iter x steps dispatches of the sweep kernel), summarised by tools/rocpd_pmc.py + tools/pmc_fold.py",
-    "workload": cfg["workload"], "N": cfg["N"], "M": cfg["M"], "batch": cfg["batch"], "steps": b["steps"], "warmup": b["warmup"],
+    "workload": cfg["workload"], "N": cfg["N"], "M": cfg["M"], "missing_rate": cfg.get("missing_rate", 0.0), "batch": cfg["batch"], "steps": b["steps"], "warmup": b["warmup"],
     "kernel": b["roofline"]["kernel"],
     "dispatches_timed": f["n"], "dispatches_doing_work": f["n_work"],
     "FETCH_SIZE_KiB_mean_per_working_launch": f["mean_work"], "FETCH_SIZE_KiB_median_per_working_launch": f["median_work"],
@@ -42,7 +43,7 @@ json.dump({
     "traffic_bytes_per_launch": traffic,
     "traffic_bytes_per_iteration": (2.0 * f["sum"] + w["sum"]) * 1024.0 / b["steps"],
     "accepted_per_launch": cfg.get("accepted_per_launch"), "columns_streamed_per_accepted": cfg.get("columns_streamed_per_accepted"),
-}, open(os.path.join(O, "%s_c4_pmc_traffic.json" % R), "w"), indent=1)
+}, open(os.path.join(O, "%s_%s_pmc_traffic.json" % (R, TAG)), "w"), indent=1)
 
 s1 = {k: work("SQ1", k) for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE")}
 s2 = {k: work("SQ2", k) for k in ("SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
@@ -58,7 +59,7 @@ XCDS = 8
 gui = s1["GRBM_GUI_ACTIVE"]["mean_work"] / XCDS
 cap = gui / 4.0 * 1024.0
 json.dump({
-    "command": cmd + " (two SQ passes)", "workload": b1["config"]["workload"], "N": b1["config"]["N"], "M": b1["config"]["M"],
+    "command": cmd + " (two SQ passes)", "workload": b1["config"]["workload"], "N": b1["config"]["N"], "M": b1["config"]["M"], "missing_rate": b1["config"].get("missing_rate", 0.0),
     "kernel": b1["roofline"]["kernel"],
     "steps": b1["steps"], "warmup": b1["warmup"], "dispatches_timed": s1["SQ_INSTS_VALU"]["n"],
     "per_working_launch_mean": {k: v["mean_work"] for k, v in {**s1, **{k: v for k, v in s2.items() if k != "GRBM_GUI_ACTIVE"}}.items()},
@@ -72,6 +73,6 @@ json.dump({
     "wait_any_share_of_wave_cycles": s2["SQ_WAIT_ANY"]["mean_work"] / s1["SQ_WAVE_CYCLES"]["mean_work"] if s1["SQ_WAVE_CYCLES"]["mean_work"] else None,
     "active_inst_any_share_of_wave_cycles": s2["SQ_ACTIVE_INST_ANY"]["mean_work"] / s1["SQ_WAVE_CYCLES"]["mean_work"] if s1["SQ_WAVE_CYCLES"]["mean_work"] else None,
     "valu_insts_per_wave": s1["SQ_INSTS_VALU"]["mean_work"] / s1["SQ_WAVES"]["mean_work"] if s1["SQ_WAVES"]["mean_work"] else None,
-}, open(os.path.join(O, "%s_c4_pmc_valu.json" % R), "w"), indent=1)
-print(open(os.path.join(O, "%s_c4_pmc_traffic.json" % R)).read())
-print(open(os.path.join(O, "%s_c4_pmc_valu.json" % R)).read())
+}, open(os.path.join(O, "%s_%s_pmc_valu.json" % (R, TAG)), "w"), indent=1)
+print(open(os.path.join(O, "%s_%s_pmc_traffic.json" % (R, TAG))).read())
+print(open(os.path.join(O, "%s_%s_pmc_valu.json" % (R, TAG))).read())
