@@ -209,10 +209,11 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
 // clobbers of the hand-over waits would otherwise make every use a scalar load of its own), the LDS arrays, the small helpers.
 // The roles are functions of their own so that each gets a register allocation of its own (the chain's four slots per lane want most
 // of the register file).
+#define W2_BEXPR pr.B
 #define W2_PROLOGUE \
     const int tid = threadIdx.x, lane = tid & 63; \
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); \
-    const uint32_t B = pr.B, bmask = B - 1u, M = pr.M; \
+    const uint32_t B = W2_BEXPR, bmask = B - 1u, M = pr.M; \
     const uint32_t MR = 2u * B, mrmask = MR - 1u; \
     const int K = pr.K, GK = pr.GK; \
     const uint32_t W = pr.W, nsh = pr.nsh, rsh = pr.rsh; \
@@ -254,10 +255,17 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     auto aborted = [&]() { return w2_ld(sh.sw + S_ABORT) != 0u; }; \
     auto ended = [&]() { return w2_ld(sh.sw + S_END) != 0u; };
 
-template <int DBG, int MISS>
+// (BC: the window as a compile-time constant -- 256, the size that is used where speed matters -- or 0: whatever the sweep's parameters say.
+// With the constant the LDS arrays are at constant addresses and the slot arithmetic is immediate: the wave's few scalar registers are not
+// spent on three dozen array bases, and a wave issues one instruction every four to five clocks whatever it is.)
+template <int DBG, int MISS, int BC>
 __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
 {
+#undef W2_BEXPR
+#define W2_BEXPR (BC ? (uint32_t)BC : pr.B)
     W2_PROLOGUE
+#undef W2_BEXPR
+#define W2_BEXPR pr.B
     // =====================================================================================================================
     // the chain: wave w holds the window slots 64 w + lane, one position per lane; wave 0 also decides
     // =====================================================================================================================
@@ -1140,7 +1148,10 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
     __syncthreads();
 
     if (wave < W2_NCH) {
-        if ((uint32_t)wave < (B >= 64u ? B / 64u : 1u)) w2_chain<DBG, MISS>(pr);
+        if ((uint32_t)wave < (B >= 64u ? B / 64u : 1u)) {
+            if (B == 256u) w2_chain<DBG, MISS, 256>(pr);
+            else w2_chain<DBG, MISS, 0>(pr);
+        }
     } else if (wave == 4) w2_folder<MISS>(pr);
     else if (wave == 5) w2_housekeeper<MISS>(pr);
     __syncthreads();
