@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "hydra_chain_last_nnz",
     # BayesW
     "hgibbs_grand_seed", "hgibbs_grand_next", "hgibbs_ars_sample", "hgibbs_w_init", "hgibbs_w_marker_stats", "hgibbs_w_set_model",
-    "hgibbs_w_reduce", "hgibbs_w_refresh_vi", "hgibbs_w_get_vi", "hgibbs_w_marker_sums", "hgibbs_w_sweep", "hgibbs_w_last_sweep_stats",
+    "hgibbs_w_reduce", "hgibbs_w_refresh_vi", "hgibbs_w_get_vi", "hgibbs_w_marker_sums", "hgibbs_w_sweep", "hgibbs_w_last_sweep_stats", "hgibbs_w_ars_device_probe",
     "hgibbs_w_get_beta", "hgibbs_w_set_beta", "hydraw_chain_create", "hydraw_chain_destroy", "hydraw_chain_set_covariates",
     "hydraw_chain_reseed_ars", "hydraw_chain_iterate", "hydraw_chain_state", "hydraw_chain_gamma", "hydraw_chain_order",
     "hydraw_chain_last_nnz", "hydraw_chain_csv_line", "hydraw_chain_restore",
@@ -162,6 +162,7 @@ def lib():
     L.hgibbs_w_marker_sums.argtypes = [vp, C.c_uint32, C.c_double, C.c_double, dp, dp, dp]
     L.hgibbs_w_sweep.argtypes = [vp, ip, C.c_double, dp, dp, C.c_double, C.POINTER(RngState), gp, ip, dp, u64p]
     L.hgibbs_w_last_sweep_stats.argtypes = [vp, C.POINTER(WSweepStats)]
+    L.hgibbs_w_ars_device_probe.argtypes = [vp, dp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, dp, dp, dp]
     L.hgibbs_w_get_beta.argtypes = [vp, dp, ip]
     L.hgibbs_w_set_beta.argtypes = [vp, dp, ip]
     L.hydraw_chain_create.argtypes = [vp, C.POINTER(WModelDesc), dp, ip, C.POINTER(vp)]

@@ -512,6 +512,41 @@ __global__ __launch_bounds__(WAVE) void k_bw_tail(BwBatchParams p)
     }
 }
 
+// diagnostic: the ARS draw of an effect on ONE lane of the device (what the event's continuation on the device would cost)
+struct BwArsProbe {
+    double d[9], beta_old, safe_limit;
+    uint32_t seed, ndraws;
+    double* out; // {100 MHz ticks, density evaluations, last draw, error}
+};
+__global__ __launch_bounds__(WAVE) void k_bw_ars_probe(BwArsProbe pr)
+{
+    if (threadIdx.x != 0) return;
+    hg::GlibcRand g;
+    g.seed(pr.seed);
+    struct U {
+        hg::GlibcRand* g;
+        __device__ double operator()() { return g->uniform(); }
+    } u{&g};
+    bw::BetaLogDensity f{pr.d[0], pr.d[1], pr.d[2], pr.d[3], pr.d[4], pr.d[5], pr.d[6], pr.d[7], pr.d[8]};
+    const double b = pr.beta_old, sl = pr.safe_limit;
+    const double xinit[4] = {b - sl / 10, b, b + sl / 20, b + sl / 10};
+    double last = 0.0;
+    unsigned long long evals = 0;
+    int err = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (uint32_t i = 0; i < pr.ndraws && !err; ++i) {
+        hg::ars::Hull hull;
+        int ne = 0;
+        err = hg::ars::sample(xinit, b - sl, b + sl, f, u, hull, last, ne);
+        evals += (unsigned long long)ne;
+    }
+    const unsigned long long t1 = wall_clock64();
+    pr.out[0] = (double)(t1 - t0);
+    pr.out[1] = (double)evals;
+    pr.out[2] = last;
+    pr.out[3] = (double)err;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1022,6 +1057,31 @@ int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const do
     b->stats.ars_evals = ars_evals;
     b->stats.device_ms = ms;
     b->stats.sums_kernel_ms = sums_ms;
+    return 0;
+}
+
+/* the ARS draw on one device lane, timed (diagnostic; see include/hgibbs.h) */
+int hgibbs_w_ars_device_probe(hgibbs_t h, const double* dens9, double beta_old, double safe_limit, uint32_t seed, uint32_t ndraws, double* us_per_draw,
+                              double* evals_per_draw, double* last_draw)
+{
+    if (!h || !dens9 || ndraws == 0) return fail("hgibbs_w_ars_device_probe: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (ensure_scratch(h, 64)) return 1;
+    BwArsProbe pr{};
+    for (int i = 0; i < 9; ++i) pr.d[i] = dens9[i];
+    pr.beta_old = beta_old;
+    pr.safe_limit = safe_limit;
+    pr.seed = seed;
+    pr.ndraws = ndraws;
+    pr.out = h->scratch;
+    k_bw_ars_probe<<<1, WAVE, 0, h->stream>>>(pr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->scratch, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch_host[3] != 0.0) return fail("hgibbs_w_ars_device_probe: ARS error code %d on the device", (int)h->scratch_host[3]);
+    if (us_per_draw) *us_per_draw = h->scratch_host[0] / 100.0 / (double)ndraws; // 100 MHz wall clock
+    if (evals_per_draw) *evals_per_draw = h->scratch_host[1] / (double)ndraws;
+    if (last_draw) *last_draw = h->scratch_host[2];
     return 0;
 }
 

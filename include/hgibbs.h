@@ -291,6 +291,12 @@ int hgibbs_w_marker_sums(hgibbs_t h, uint32_t marker, double beta_old, double al
 int hgibbs_w_sweep(hgibbs_t h, const int32_t* order_host, double alpha, const double* sigmaG, const double* pi, double sumSigmaG,
                    hgibbs_rng_state* rng, hgibbs_grand_state* ars_rng, int32_t* cass_host, double* beta_sqnorm, uint64_t* nnz_updates);
 int hgibbs_w_last_sweep_stats(hgibbs_t h, hgibbs_w_sweep_stats* out);
+/* diagnostic: the adaptive-rejection draw of an effect (src/BayesW.cpp:1562-1582, src/BayesW_arms.cpp:135-242) on ONE device lane,
+ * `ndraws` times on the density beta_dens with the nine parameters dens9 = {alpha, sigmaG, sum_failure, sd, mean / sd, mixture value,
+ * vi_0, vi_1, vi_2}, abscissae and bounds as the sweep sets them from beta_old and safe_limit: microseconds per draw (device clock),
+ * density evaluations per draw, the last draw.  What the event's continuation on the device would cost. */
+int hgibbs_w_ars_device_probe(hgibbs_t h, const double* dens9, double beta_old, double safe_limit, uint32_t seed, uint32_t ndraws,
+                              double* us_per_draw, double* evals_per_draw, double* last_draw);
 int hgibbs_w_get_beta(hgibbs_t h, double* beta, int32_t* components);
 int hgibbs_w_set_beta(hgibbs_t h, const double* beta, const int32_t* components);
 
