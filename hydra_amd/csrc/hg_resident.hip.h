@@ -127,6 +127,7 @@ struct ResParams {
     int dbg;
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
     int tune;   // experiments (option res_tune): bits 0-1: priority of the younger wave of each SIMD (waves 4 .. 7) in the refill
+    int early_advance; // second walker: a walk that has run out of dots moves the window on at once (a message that only advances) when at least this many positions have passed (0: it waits)
     int walker; // 2: the second walker (hg_walker2.hip.h: one wave walks the chain, the others serve it), else the first
     const uint32_t* pred; // the sweep positions whose marker has a non-zero effect at sweep start (predicted events), ascending, then 16 sentinels 0xffffffff
     int all_ada; // 1: no marker is frozen out (adaV all ones, the usual case): a marker's uniform is its distance from the cursor

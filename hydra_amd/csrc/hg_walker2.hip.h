@@ -220,6 +220,7 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     const double n_total = pr.n_total, n_minus_1 = pr.n_minus_1, i_2sigE = pr.i_2sigE, eps_sum = pr.eps_sum, fx_unscale = pr.fx_unscale; \
     const unsigned long long timeout = pr.timeout; \
     const bool pivots = pr.pivots != 0; \
+    const uint32_t early_advance = (uint32_t)pr.early_advance; \
     const uint32_t rng_idx0 = pr.rng_idx; \
     ResMsg* const msg = pr.msg; \
     ResState* const state = pr.state; \
@@ -712,7 +713,11 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         }
         lap(3);
         if (failed) break;
-        if (!found && Fs < Sx) {
+        // (every position with a dot has passed and the walk needs dots that are still on their way: if enough positions have passed, the window
+        // moves on NOW -- a message that only advances -- so that the streaming workgroups refill behind it while the walk waits)
+        const uint32_t early_thr = early_advance;
+        const bool early = !found && Fs < Sx && early_thr != 0u && Fs - C >= early_thr;
+        if (!found && Fs < Sx && !early) {
             // every position with a dot has passed: the walk needs dots that are still on their way
             ++n_refold;
             if (!wait_seen(fpub_seen, S_FPUB, Fs + 1u)) break;
@@ -721,7 +726,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             continue;
         }
         // ---- the message: an event at qpos, or a round that only moves the window on ----
-        const uint32_t ncons = found ? qpos - C + 1u : Sx - C;
+        const uint32_t ncons = found ? qpos - C + 1u : (early ? Fs - C : Sx - C);
         const uint32_t Cn = C + ncons;
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         const double dbeta = found ? q_bold - q_bnew : 0.0;

@@ -157,6 +157,7 @@ struct hgibbs_ctx {
     bool res_attr_set[8] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
     bool res_dead = false;     // a resident kernel did not come back even after the abort word: the stream (and the handle) cannot be used any more
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
+    int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
@@ -1226,6 +1227,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
         h->window = (uint32_t)value;
     } else if (!std::strcmp(name, "pivots")) {
         h->res_pivots = value != 0;
+    } else if (!std::strcmp(name, "early_advance")) {
+        if (value < 0 || value > 255) return fail("early_advance must be in [0,255]");
+        h->res_early = (int)value;
     } else if (!std::strcmp(name, "res_tune")) {
         h->res_tune = (int)value;
     } else if (!std::strcmp(name, "walker")) {
@@ -1467,6 +1471,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     }
     p.pred = h->pred;
     p.tune = h->res_tune;
+    p.early_advance = h->res_early;
     {
         // the predicted events of this sweep, in sweep order (read by the streaming workgroups and by the walker)
         const uint32_t nchunk = (h->M + PRED_CHUNK - 1) / PRED_CHUNK;
