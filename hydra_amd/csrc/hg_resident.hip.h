@@ -429,6 +429,8 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     unsigned long long* const rlds = reinterpret_cast<unsigned long long*>(smem + rs_miss_racc_off(B)); // build MISS: [position - Sx] fixed-point sum of eps over the column's missing calls
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + (MISS ? rs_miss_ring_off(B, T) : 512 + (size_t)B * 97)); // [B][64 * T] codes of the window columns
     double* const epsl = reinterpret_cast<double*>(smem + rs_epsl_off(B, T));           // build MISS: the eps slice by individual (see rs_epsl_off)
+    uint32_t* const fin_cnt = reinterpret_cast<uint32_t*>(smem + 320);                  // waves of this round that are through their atomics
+    if (tid == 0) *fin_cnt = 0u;
     const bool timing = DBG && wg == 0 && tid == 0;
     unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(smem + 384); // [8] stage clocks of the debug build (in LDS: sixteen registers less)
     unsigned long long tmark = timing ? wall_clock64() : 0ull;
@@ -840,10 +842,23 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
             __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
         }
-        wait_vmcnt<0>();
+        // Only the waves that sent something wait for their atomics to be performed (~0.6 us); the last of them to be through counts the
+        // batch in for the walker.  The others go straight on to the next message -- which a wave polls that has nothing to drain -- so the
+        // drain hides behind the wait for the walker instead of standing in front of it.
+        {
+            const uint32_t nfin = p.pivots ? (uint32_t)RS_WAVES : (nnew + 63u) / 64u < 1u ? 1u : ((nnew + 63u) / 64u > (uint32_t)RS_WAVES ? (uint32_t)RS_WAVES : (nnew + 63u) / 64u);
+            if ((uint32_t)wave < nfin) {
+                wait_vmcnt<0>();
+                if (lane == 0) {
+                    const uint32_t got = __hip_atomic_fetch_add(fin_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+                    if (got == nfin) {
+                        __hip_atomic_store(fin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (the next round's waves count behind this round's barriers)
+                        __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
+                    }
+                }
+            }
+        }
         lap(5);
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
         lap(6);
         if (timing) p.trace[7 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
         C = Cn;
@@ -854,7 +869,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         // ---- wait for the walker's next message (one lane polls; everybody else sleeps at the barrier) ----
         ++seq;
         if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 3u;
-        if (tid == 0) {
+        if (tid == RS_BLOCK - WAVE) { // (the last wave: it never has atomics of the refill to drain)
             const ResMsg* m = p.msg + (seq % RS_MSG);
             const unsigned long long t0 = wall_clock64();
             uint32_t npoll = 0;
