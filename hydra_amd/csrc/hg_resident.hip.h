@@ -151,9 +151,12 @@ struct ResParams {
 constexpr uint32_t RX_RING = 1024;
 constexpr size_t RX_GBOX = 0;
 constexpr size_t RX_RBOX = RX_GBOX + (size_t)RX_MAXR * 2 * RS_BMAX * 16;
-constexpr size_t RX_BYTES = RX_RBOX + (size_t)RX_MAXR * RX_RING * 32;
+//   hbox[src][2] u64                 the probe launch's handshake (rs_probe_peers): "my grid is resident" and "so is everybody's, as far as I see"
+constexpr size_t RX_HBOX = RX_RBOX + (size_t)RX_MAXR * RX_RING * 32;
+constexpr size_t RX_BYTES = RX_HBOX + (size_t)RX_MAXR * 2 * 8;
 __device__ __forceinline__ unsigned long long* rx_gbox(unsigned char* mb, int src, uint32_t par) { return reinterpret_cast<unsigned long long*>(mb + RX_GBOX) + ((size_t)src * 2 + par) * RS_BMAX * 2; } // two words per column (build MISS uses both)
 __device__ __forceinline__ unsigned long long* rx_rbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_RBOX) + (size_t)src * RX_RING * 4; } // four words per position: the halves of s1 and (build MISS) of R
+__device__ __forceinline__ unsigned long long* rx_hbox(unsigned char* mb, int src) { return reinterpret_cast<unsigned long long*>(mb + RX_HBOX) + (size_t)src * 2; }
 __device__ __forceinline__ unsigned long long rx_rtag(unsigned long long sweep, uint32_t batch) { return (0x80000000ull | ((sweep & 0x7ffull) << 20) | (unsigned long long)(batch & 0xfffffu)) << 32; }
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -2019,11 +2022,50 @@ __device__ __forceinline__ bool rs_rendezvous(const ResParams& p, unsigned char*
     return ok;
 }
 
+// Several ranks, probe launch (hgibbs.hip, resident_probe): are ALL ranks' grids resident AT THE SAME TIME?  A rank's own rendezvous cannot
+// tell: two processes that share a device may have their kernels run one after the other, each grid resident at once, and each sweep
+// would wait its full time-out for a peer that has not started.  The walkers shake hands through the mailboxes in two steps -- "my grid
+// is resident" to every peer, then, when every peer has said so, "everybody's is, as far as I see" -- while every workgroup of the grid
+// stays where it is; a rank that has every peer's second word was resident together with all of them at the moment the last first word
+// was sent.  Both waits are bounded (rdv_timeout); a rank that gives up says so in state->error (6) and the host's all-reduce tells the others.
+__device__ __forceinline__ void rs_probe_peers(const ResParams& p)
+{
+    if (threadIdx.x != 0) return; // (the workgroup keeps its compute unit as long as one wave is here)
+    unsigned long long* const done = p.progress + 4;
+    if (blockIdx.x == p.W) {
+        const unsigned long long tag = 0x5a00000000000000ull | (p.sweep_id << 8);
+        uint32_t ok = 1u;
+        for (unsigned long long phase = 1ull; phase <= 2ull && ok; ++phase) {
+            for (int r = 0; r < p.nranks; ++r)
+                if (r != p.rank) __hip_atomic_store(rx_hbox(p.mbox[r], p.rank) + (phase - 1ull), tag | phase, HG_RLX_SYSTEM);
+            const unsigned long long t0 = wall_clock64();
+            for (int r = 0; r < p.nranks && ok; ++r) {
+                if (r == p.rank) continue;
+                while (__hip_atomic_load(rx_hbox(p.mbox[p.rank], r) + (phase - 1ull), HG_RLX_SYSTEM) != (tag | phase)) {
+                    if (wall_clock64() - t0 > p.rdv_timeout) {
+                        ok = 0u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        if (!ok) atomicMax(&p.state->error, 6u);
+        __hip_atomic_store(done, 1ull, HG_RLX_AGENT);
+    } else {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(done, HG_RLX_AGENT) == 0ull && wall_clock64() - t0 < 4ull * p.rdv_timeout + 100000000ull) __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 template <int T, int DBG, int MISS>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p, const ResParams* pg)
 {
     if (!rs_rendezvous(p, hg_smem)) return;
-    if (p.M == 0xffffffffu) return; // (a probe launch: is the grid resident at once -- hgibbs.hip, resident_probe)
+    if (p.M == 0xffffffffu) { // (a probe launch: is the grid resident at once, and together with the peers' -- hgibbs.hip, resident_probe)
+        if (p.nranks > 1) rs_probe_peers(p);
+        return;
+    }
     if (blockIdx.x < p.W) res_streamer<T, DBG, MISS>(p, hg_smem);
     else if (p.walker == 2) res_walker2<DBG, MISS>(*pg); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
     else res_walker<DBG, MISS>(*pg, hg_smem);

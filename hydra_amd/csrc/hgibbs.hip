@@ -156,6 +156,8 @@ struct hgibbs_ctx {
     int res_walker = 0;       // option walker: 0 auto (the second where it applies), 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
     bool res_attr_set[8] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
     bool res_dead = false;     // a resident kernel did not come back even after the abort word: the stream (and the handle) cannot be used any more
+    uint32_t res_probed_w = 0;     // several ranks: the grid size the probe launch has found resident together with the peers' (0: not yet)
+    unsigned long long res_probe_id = 0;
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
@@ -1360,10 +1362,11 @@ static int resident_kernel(hgibbs_ctx* h, const ResPlan& pl, void (**out)(ResPar
     return 0;
 }
 
-// Several ranks: is this rank's resident grid resident at once?  A launch of the sweep kernel that ends behind its start-of-kernel
-// rendezvous (W = the grid, M = 0 markers -- nothing else runs), then one scalar all-reduce: the ranks run the resident engine only if
-// every rank's grid is.  (One rank finds out by itself, inside the sweep's own launch: hgibbs_sweep falls back then.)  Returns non-zero
-// when some rank's grid is not resident.
+// Several ranks: is this rank's resident grid resident at once, and at the same time as every peer's?  A launch of the sweep kernel that
+// ends behind its start-of-kernel rendezvous and the walkers' handshake through the mailboxes (rs_probe_peers; M = 0xffffffff -- nothing
+// else runs), then one scalar all-reduce: the ranks run the resident engine only if every rank says yes.  Asked once per grid size.  (One
+// rank finds out by itself, inside the sweep's own launch: hgibbs_sweep falls back then.)  Returns non-zero when some rank's grid is not
+// resident -- e.g. ranks that share one device and whose kernels the device runs one after the other.
 static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
 {
     void (*kern)(ResParams, const ResParams*) = nullptr;
@@ -1375,6 +1378,10 @@ static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
     p.state = h->res_state;
     p.progress = h->res_progress;
     p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8);
+    p.nranks = h->nranks > 1 ? h->nranks : 1;
+    p.rank = h->nranks > 1 ? h->rank : 0;
+    for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
+    p.sweep_id = ++h->res_probe_id; // (the ranks probe alike: the handshake's words of an earlier probe never match)
     const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), std::max(rs_walker_lds(pl.B), rs_walker2_lds(pl.B)));
     if (hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream) != hipSuccess || hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream) != hipSuccess) return 1;
     kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p, h->res_params);
@@ -1388,6 +1395,7 @@ static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
         h->res_not_resident = true;
         return 1;
     }
+    h->res_probed_w = pl.W + 1; // (this grid has been seen resident together with every peer's: later sweeps of the same plan launch without asking again)
     return 0;
 }
 
@@ -1697,7 +1705,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
                 plan.ok = false;
             }
             // (every rank has the same answer now) a rank whose grid is not resident at once must be known BEFORE its peers wait for it
-            if (plan.ok && resident_probe(h, plan)) {
+            if (plan.ok && h->res_probed_w != plan.W + 1 && resident_probe(h, plan)) {
                 plan.ok = false;
                 why = "some rank's resident grid is not resident at once (a shared device)";
             }

@@ -151,6 +151,42 @@ def test_ranks_one_gpu_resident_engine(oracle, M, N, world, opts, iters, miss):
 
 
 # ---- BayesW sharded the same way: per-batch row sums and the density sums add over the ranks ----------
+def test_two_ranks_whose_grids_cannot_share_the_device_finish_on_the_batch_engine(oracle):
+    """Two ranks on ONE device, each with a shard of 131 tiles: 2 x 132 workgroups of 153 KB LDS cannot be resident together on 256
+    compute units (the device runs the two kernels one after the other, each grid resident at once -- so a rank's own rendezvous says
+    nothing).  With default options the probe launch's handshake between the walkers finds out before any sweep has started, the
+    ranks agree, and every sweep runs on the batch engine: no time-out, no error, the oracle's chain."""
+    import time
+    import torch.multiprocessing as mp
+    import orc
+    from hydra_amd import synth
+    M, N, iters, world = 96, 2 * 131 * 1024, 2, 2
+    geno = synth.make_genotypes(M, N, seed=81, missing_rate=0.0)
+    y, _ = synth.make_phenotype(geno, seed=82, causal_frac=0.05)
+    bed = synth.pack_bed_columns(geno)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, {}, q)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert len(r) == 10, "rank %s failed: %s" % (r[0], r[1])
+        assert r[7] == [1], "engines used: %s" % (r[7],)
+    res.sort(key=lambda r: r[0])
+    ref = orc.Chain(oracle, bed, N, y, seed=1222)
+    for _ in range(iters):
+        ref.iterate()
+    tol = lambda a, b: np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-9 * np.maximum(1.0, np.abs(np.asarray(b))))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.array_equal(res[0][2], ref.arr("components")) and tol(res[0][1], ref.arr("beta")) and tol(res[0][3], ref.sigmaE)
+    assert tol(np.concatenate([r[5] for r in res]), ref.arr("eps"))
+
+
 def _worker_bw(rank, world, port, bed, y, fail, X, N, iters, q):
     import torch
     import torch.distributed as dist

@@ -4,6 +4,10 @@ vector registers v224 .. v255 (and the lanes' per-set values in v216 .. v220), n
 instructions the compiler does not see as loads; the kernel carries amdgpu_num_vgpr(216), so the compiler must never allocate them.  This script verifies exactly that on the emitted
 code: in every k_sweep_resident kernel, no instruction outside an inline-assembly block names a register >= v216, and inside
 inline assembly only the expected instructions do (global_load_dword[x2], v_and_b32, v_mov_b32, v_readlane_b32).
+Callees are compiled without that cap, so the kernel body may call nothing but the walkers (res_walker, res_walker2: the walker's
+workgroup has no column loads in flight and everything the walkers call is reached from there only): every function symbol the body
+materialises must be one of those and every s_swappc_b64 must have such a symbol, so a helper of the streaming path that stopped
+being inlined fails this check instead of silently overwriting the landing registers.
 usage: asm_check_loads.py file.s   (exit 1 on a violation)"""
 import re
 import sys
@@ -20,14 +24,16 @@ def vregs(s):
     return out
 
 
+funcs = {m.group(1) for t in text for m in [re.match(r"^\s*\.type\s+(\S+),@function", t)] if m}
 bad = checked = 0
 i, n = 0, len(text)
 while i < n:
     m = re.match(r"^(\S*k_sweep_resident\S*):\s", text[i])
     if m and not text[i].startswith("."):
         name, inasm, loads, reads = m.group(1), False, 0, 0
+        calls, targets = 0, []
         j = i + 1
-        while j < n and "s_endpgm" not in text[j]:
+        while j < n and not text[j].startswith(".Lfunc_end"):  # (the body may hold several s_endpgm: early returns)
             t = text[j].strip()
             if "#ASMSTART" in t:
                 inasm = True
@@ -35,6 +41,14 @@ while i < n:
                 inasm = False
             elif t and not t.startswith((";", ".")) and not t.endswith(":"):
                 t = t.split(";")[0]
+                if t.split()[0] in ("s_swappc_b64", "s_setpc_b64", "s_call_b64"):
+                    calls += 1
+                for sym in re.findall(r"(\S+)@rel32@lo", t):
+                    if sym in funcs:
+                        targets.append(sym)
+                        if "res_walker" not in sym:
+                            print("%s line %d: the kernel body calls %s (only the walkers may be called: callees do not honour the register cap)" % (name[:48], j + 1, sym[:60]))
+                            bad += 1
                 hi = {r for r in vregs(t) if r >= LIMIT}
                 if hi and not inasm:
                     print("%s line %d: %s   (names v%s outside inline assembly)" % (name[:48], j + 1, t.strip()[:80], sorted(hi)[:4]))
@@ -50,6 +64,10 @@ while i < n:
                         bad += 1
             j += 1
         print("%s: %d loads into / %d reads of the landing registers, all inside inline assembly" % (name, loads, reads))
+        print("  calls in the body: %d, function symbols materialised: %s" % (calls, sorted({re.sub(r"^_ZN2hg\d+", "", x)[:12] for x in targets})))
+        if calls > len(targets):
+            print("  ... a call without a walker symbol of its own: its target cannot be checked")
+            bad += 1
         if loads == 0 or reads == 0:
             print("  ... but none were found: the check does not see what it is meant to check")
             bad += 1
