@@ -52,7 +52,12 @@ constexpr int RS_FG = 4, RS_FN = 256;      // the walker's tabulated bound: grou
 constexpr int RX_MAXR = 8;                // ranks the engine shards over (one node of eight GPUs; more fall back to the batch engine): the walker keeps a load per peer in flight
 constexpr int RS_EVENT_FLAG = 0x100;      // in comp[] during a sweep: the marker was an event (the walker wrote its component); cleared by k_res_finish
 
-enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has); RS_LAST is a flag bit
+enum { RS_EVENT = 0, RS_ADVANCE = 1, RS_ABORT = 2, RS_PIVOT = 3, RS_ANNOUNCE = 4, RS_ANNOUNCED = 5, RS_LAST = 8 }; // message kinds (RS_PIVOT: an event whose Gram terms the walker already has or has asked for); RS_LAST is a flag bit
+// RS_ANNOUNCE (second walker): "position C + ncons - 1 WILL be an event -- its marker's effect is non-zero, so whatever is drawn changes it --
+// send its Gram terms now".  Nothing else happens: the window stays, no batch is counted.  The announcement stands in the NEXT message's
+// slot with that message's number; the message itself (RS_ANNOUNCED: an event whose Gram terms a workgroup that saw the announcement
+// has sent already -- one that was busy and never saw it sends them now) overwrites it when the new effect has been drawn, so the Gram
+// terms' way to the walker (~3.5 us) runs beside the walker's draw instead of behind it.
 
 // tag = seq << 32 | kind << 28 | check << 12 | ncons: the walker consumed `ncons` positions; RS_EVENT: the last of them changed its
 // effect by -dbeta (dbeta = old - new)
@@ -128,6 +133,7 @@ struct ResParams {
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
     int tune;   // experiments (option res_tune): bits 0-1: priority of the younger wave of each SIMD (waves 4 .. 7) in the refill
     int early_advance; // second walker: a walk that has run out of dots moves the window on at once (a message that only advances) when at least this many positions have passed (0: it waits)
+    int announce; // second walker: 1: an event that is certain (a marker with a non-zero effect) is announced to the streaming workgroups before its draw (RS_ANNOUNCE)
     int walker; // 2: the second walker (hg_walker2.hip.h: one wave walks the chain, the others serve it), else the first
     const uint32_t* pred; // the sweep positions whose marker has a non-zero effect at sweep start (predicted events), ascending, then 16 sentinels 0xffffffff
     int all_ada; // 1: no marker is frozen out (adaV all ones, the usual case): a marker's uniform is its distance from the cursor
@@ -482,6 +488,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
     uint32_t pcur = 0; // index into p.pred of the first predicted position at or behind the cursor
     const rs_cu32* const pred4 = (const rs_cu32*)p.pred; // (constant address space: uniform indices make scalar loads)
     uint32_t kind = RS_ADVANCE, ncons = 0;
+    bool gram_sent = false; // the Gram terms of the event the next message brings have been sent (on its announcement)
     bool last = M == 0;
     double dbeta = 0.0;
     // Wave v streams the positions p = v (mod 8); its k-th one, v + 8 k, lives in register set k mod RS_PF from the moment it
@@ -513,26 +520,60 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         [&]<int... R>(std::integer_sequence<int, R...>) { (load_set(std::integral_constant<int, R>{}, (uint32_t)R, id0), ...); }(std::make_integer_sequence<int, RS_PF>{});
         if (lane < RS_PF) lane_load(mp, pos_of((uint32_t)lane + RS_PF));
     }
+    // wait for the walker's message number seq (one lane polls; everybody else sleeps at the barrier); behind an announcement: for the
+    // message that overwrites it
+    auto take_message = [&](bool announced) {
+        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 3u;
+        if (tid == RS_BLOCK - WAVE) { // (the last wave: it never has atomics of the refill to drain)
+            const ResMsg* m = p.msg + (seq % RS_MSG);
+            const unsigned long long t0 = wall_clock64();
+            uint32_t npoll = 0;
+            u4_t v;
+            for (;;) {
+                v = rs_load16(m);
+                if (v.y == seq && ((v.x >> 12) & 0xffffu) == rs_msg_check(seq, v.z, v.w) && !(announced && ((v.x >> 28) & 7u) == (uint32_t)RS_ANNOUNCE)) break;
+                if (wall_clock64() - t0 > p.timeout || ((++npoll & 255u) == 0u && __hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull)) { // (or the host gave the sweep up)
+                    v.x = (uint32_t)RS_ABORT << 28;
+                    v.y = seq;
+                    atomicMax(&p.state->error, 3u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            lmsg[0] = ((unsigned long long)v.y << 32) | v.x;
+            lmsg[1] = ((unsigned long long)v.w << 32) | v.z;
+        }
+        __syncthreads();
+        const unsigned long long tag = lmsg[0];
+        dbeta = __longlong_as_double((long long)lmsg[1]);
+        const uint32_t kf = (uint32_t)(tag >> 28) & 0xfu;
+        kind = kf & 7u;
+        last = (kf & RS_LAST) != 0u;
+        ncons = (uint32_t)tag & 0xfffu;
+        lap(0);
+        if (timing) p.trace[4 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+    };
     for (;;) {
-        const bool upd = kind == RS_EVENT || kind == RS_PIVOT; // RS_PIVOT: the walker has this event's Gram terms already
-        const bool with_gram = kind == RS_EVENT;
+        const bool ann = kind == RS_ANNOUNCE;
+        const bool upd = kind == RS_EVENT || kind == RS_PIVOT || kind == RS_ANNOUNCED; // RS_PIVOT: the walker has this event's Gram terms already
+        const bool with_gram = kind == RS_EVENT || ann || (kind == RS_ANNOUNCED && !gram_sent); // (announced while this workgroup was busy: the announcement was overwritten unseen)
         // (progress words: a store in front of a barrier or a vmcnt(0) wait makes it wait for the store's round trip -- workgroup 0 would be the
         // slowest of all; the timed build keeps only the stores that stand in front of a poll)
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
-        const uint32_t Cn = C + ncons;
+        const uint32_t Cn = ann ? C : C + ncons;
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         const uint32_t nnew = Sn - Sx;
         uint32_t count_w = (Sn > (uint32_t)wave ? (Sn - (uint32_t)wave + 7u) / 8u : 0u) - nk; // this wave's positions in [Sx, Sn)
-        cols_landed(); // issued at the end of the last round: nothing to wait for (and no Gram atomic in flight yet)
+        cols_landed(); // issued at the end of the last round: nothing to wait for (and no Gram atomic in flight yet; behind an announcement they went out a draw ago)
 
-        if (upd) {
+        if (upd || ann) {
             const uint32_t slotq = q & bmask;
             uint32_t xq[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) xq[t] = ring[slotq * 64u * T + (uint32_t)lane * T + t];
             const double2 mq = meta[slotq];
-            if (tid < 16) { // the update's pair table (read behind the Gram terms, below)
+            if (upd && tid < 16) { // the update's pair table (read behind the Gram terms, below)
                 const double av = mq.x, sd = mq.y, db = dbeta;
                 const double v0 = -(av * sd * db), v1 = db * (1.0 - av) * sd, v2 = db * (2.0 - av) * sd;
                 // (window codes: the x form 00 / 01 / 11 = genotype 0 / 1 / 2; 10 = missing call, addend 0)
@@ -635,12 +676,20 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
             // ---- a8 (src/BayesRRm.cpp:1976-2010,2022,2471): eps += {v0, v1, v2, 0}[code] on the registers of every wave, while the
             // Gram atomics are on their way (an LDS-only barrier: __syncthreads() would wait for them to be performed) ----
-            rs_lds_barrier();
+            rs_lds_barrier(); // (an announcement: everybody has read the message before the polling lane writes the next one)
+            if (upd) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
-            eps_to_lds(); // (build MISS: read by the refill below, behind a barrier)
+                for (int t = 0; t < T; ++t) apply_update16_lds(xq[t], tab, e[t]);
+                eps_to_lds(); // (build MISS: read by the refill below, behind a barrier)
+            }
             lap(1);
             if (timing) p.trace[5 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+        }
+        gram_sent = ann;
+        if (ann) { // the message proper takes the announcement's place: same number, same slot
+            take_message(true);
+            if (kind == RS_ABORT) break;
+            continue;
         }
 
         // ---- a4 (src/BayesRRm.cpp:1766-1809) of the columns that refill the window, against eps as it is now ----
@@ -869,37 +918,9 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         if (last) break;
         lap(7);
 
-        // ---- wait for the walker's next message (one lane polls; everybody else sleeps at the barrier) ----
+        // ---- wait for the walker's next message ----
         ++seq;
-        if (wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 3u;
-        if (tid == RS_BLOCK - WAVE) { // (the last wave: it never has atomics of the refill to drain)
-            const ResMsg* m = p.msg + (seq % RS_MSG);
-            const unsigned long long t0 = wall_clock64();
-            uint32_t npoll = 0;
-            u4_t v;
-            for (;;) {
-                v = rs_load16(m);
-                if (v.y == seq && ((v.x >> 12) & 0xffffu) == rs_msg_check(seq, v.z, v.w)) break;
-                if (wall_clock64() - t0 > p.timeout || ((++npoll & 255u) == 0u && __hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull)) { // (or the host gave the sweep up)
-                    v.x = (uint32_t)RS_ABORT << 28;
-                    v.y = seq;
-                    atomicMax(&p.state->error, 3u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            lmsg[0] = ((unsigned long long)v.y << 32) | v.x;
-            lmsg[1] = ((unsigned long long)v.w << 32) | v.z;
-        }
-        __syncthreads();
-        const unsigned long long tag = lmsg[0];
-        dbeta = __longlong_as_double((long long)lmsg[1]);
-        const uint32_t kf = (uint32_t)(tag >> 28) & 0xfu;
-        kind = kf & 7u;
-        last = (kf & RS_LAST) != 0u;
-        ncons = (uint32_t)tag & 0xfffu;
-        lap(0);
-        if (timing) p.trace[4 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
+        take_message(false);
         if (kind == RS_ABORT) break;
     }
 

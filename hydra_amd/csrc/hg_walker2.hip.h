@@ -221,6 +221,7 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     const unsigned long long timeout = pr.timeout; \
     const bool pivots = pr.pivots != 0; \
     const uint32_t early_advance = (uint32_t)pr.early_advance; \
+    const bool announce = pr.announce != 0 && pr.pivots == 0; \
     const uint32_t rng_idx0 = pr.rng_idx; \
     ResMsg* const msg = pr.msg; \
     ResState* const state = pr.state; \
@@ -300,7 +301,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
     uint32_t seq = 0, nev = 0, pi = 0, evn = 0, pf_n = 0, gpos = rng_idx0, blk = 1u;
     uint32_t rdone_seen = 0, wpub_seen = 0, evw_seen = 0, pld_seen = W2_PRED, fpub_seen = 0, mpub_seen = m0;
     unsigned long long cm[W2_NCH] = {0ull, 0ull, 0ull, 0ull}; // candidates among the tested positions [C, Fs), by chain wave
-    uint32_t n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0, n_pred = 0;
+    uint32_t n_rounds = 0, n_events = 0, n_adv = 0, n_nnz = 0, n_chunks = 0, n_refold = 0, n_pivots = 0, n_pred = 0, n_ann = 0;
     uint32_t err = 0;
     bool failed = false;
     unsigned long long tacc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -603,7 +604,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         // the generator: the words a decision can reach exist
         if (gpos + B + 96u > blk * (uint32_t)MT_N && !wait_seen(blk, S_BLK, (gpos + B + 96u + (uint32_t)MT_N - 1u) / (uint32_t)MT_N)) break;
         ++n_chunks;
-        bool found = false;
+        bool found = false, announced = false;
         uint32_t qpos = 0, q_consumed = 0;
         int q_k = 0;
         double q_bnew = 0.0, q_bold = 0.0;
@@ -635,6 +636,13 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 const int ga_v = sh.ga[ms];
                 const uint32_t word_v = sh.mt[upos];
                 const double bold = w2_uni(bold_v);
+                // a marker whose effect is non-zero WILL be an event (whatever is drawn changes the effect, and nothing in front of it is one):
+                // the streaming workgroups are asked for its Gram terms now -- they travel while the draw is made (RS_ANNOUNCE; the slot
+                // is free: flow control as for the message itself, and never waited for here)
+                if (announce && !announced && bold != 0.0 && qc + 1u < Sx && (seq + 6u <= (uint32_t)RS_MSG || rdone_seen >= seq + 6u - (uint32_t)RS_MSG)) {
+                    if (lane == 0) rs_store16(msg + ((seq + 1u) % RS_MSG), rs_u4(rs_msg_word0((uint32_t)RS_ANNOUNCE, qc - C + 1u, seq + 1u, 0u, 0u), seq + 1u, 0u, 0u));
+                    announced = true;
+                }
                 const int g0 = w2_uni(ga_v & 0x0fffffff) * K;
                 const double prob = (double)mt_temper(word_v) * (1.0 / 4294967296.0);
                 // a5 (src/BayesRRm.cpp:1859-1921) over the lanes: lane x < K holds logL_x; lane 8 kk + l the term exp(logL_l - logL_kk)
@@ -730,7 +738,8 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         const uint32_t Cn = C + ncons;
         const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
         const double dbeta = found ? q_bold - q_bnew : 0.0;
-        const bool is_event = found && dbeta != 0.0;
+        const bool changed = found && dbeta != 0.0;
+        const bool is_event = changed || announced; // (announced and drawn the very same effect again: an event that changes nothing -- the Gram terms have been asked for)
         const bool predicted = found && q_bold != 0.0;
         // a predicted pivot whose Gram terms came with the columns: the oldest batch with columns behind it lists it
         bool pivot = false;
@@ -744,7 +753,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         ++seq;
         ++n_rounds;
         if (lane == 0) {
-            const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE)) | (Cn >= M ? (uint32_t)RS_LAST : 0u);
+            const uint32_t kf = (pivot ? (uint32_t)RS_PIVOT : (announced ? (uint32_t)RS_ANNOUNCED : (is_event ? (uint32_t)RS_EVENT : (uint32_t)RS_ADVANCE))) | (Cn >= M ? (uint32_t)RS_LAST : 0u);
             const unsigned long long db = (unsigned long long)__double_as_longlong(dbeta);
             if (DBG) {
                 w2_gst(trace + (2 * RS_TRACE + (seq - 1u) % RS_TRACE), wall_clock64());
@@ -771,8 +780,9 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         }
         if (is_event) {
             ++n_events;
-            ++n_nnz;
+            if (changed) ++n_nnz;
             if (predicted) ++n_pred;
+            if (announced) ++n_ann;
         } else
             ++n_adv;
         const uint32_t piq = pi;
@@ -848,7 +858,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             state->nnz = n_nnz;
             state->chunks = n_chunks;
             state->refolds = n_refold;
-            state->pivots = n_pivots;
+            state->pivots = n_pivots + n_ann; // (events whose Gram terms the walker did not have to wait a whole round trip for: predicted pivots, or announced)
             state->predicted = n_pred;
             if (DBG)
                 for (int i = 0; i < 8; ++i) state->t[i] = tacc[i];

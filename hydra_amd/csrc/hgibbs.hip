@@ -160,6 +160,7 @@ struct hgibbs_ctx {
     unsigned long long res_probe_id = 0;
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_early = 24;       // option early_advance (ResParams::early_advance)
+    int res_announce = 1;     // option announce (ResParams::announce)
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
@@ -1232,6 +1233,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "early_advance")) {
         if (value < 0 || value > 255) return fail("early_advance must be in [0,255]");
         h->res_early = (int)value;
+    } else if (!std::strcmp(name, "announce")) {
+        h->res_announce = value != 0;
     } else if (!std::strcmp(name, "res_tune")) {
         h->res_tune = (int)value;
     } else if (!std::strcmp(name, "walker")) {
@@ -1480,6 +1483,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.pred = h->pred;
     p.tune = h->res_tune;
     p.early_advance = h->res_early;
+    p.announce = h->res_announce;
     {
         // the predicted events of this sweep, in sweep order (read by the streaming workgroups and by the walker)
         const uint32_t nchunk = (h->M + PRED_CHUNK - 1) / PRED_CHUNK;
