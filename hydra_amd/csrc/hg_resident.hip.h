@@ -2010,6 +2010,7 @@ __global__ __launch_bounds__(256) void k_res_finish(ResParams p)
 } // namespace hg
 
 #include "hg_walker2.hip.h"
+#include "hg_streamer2.hip.h"
 
 namespace hg {
 
@@ -2089,6 +2090,20 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LI
     }
     if (blockIdx.x < p.W) res_streamer<T, DBG, MISS>(p, hg_smem);
     else if (p.walker == 2) res_walker2<DBG, MISS>(*pg); // pg: the same parameters in device memory (a reference the called function can read with scalar loads)
+    else res_walker<DBG, MISS>(*pg, hg_smem);
+}
+
+// the same grid with the streaming workgroups' second form (hg_streamer2.hip.h: the refill's dots as integer matrix products)
+template <int T, int DBG, int MISS>
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RL_VGPR_LIMIT))) void k_sweep_limb(ResParams p, const ResParams* pg)
+{
+    if (!rs_rendezvous(p, hg_smem)) return;
+    if (p.M == 0xffffffffu) {
+        if (p.nranks > 1) rs_probe_peers(p);
+        return;
+    }
+    if (blockIdx.x < p.W) res_streamer_limb<T, DBG, MISS>(p, hg_smem);
+    else if (p.walker == 2) res_walker2<DBG, MISS>(*pg);
     else res_walker<DBG, MISS>(*pg, hg_smem);
 }
 

@@ -154,13 +154,14 @@ struct hgibbs_ctx {
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
     int res_walker = 0;       // option walker: 0 auto (the second where it applies), 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
-    bool res_attr_set[8] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
+    bool res_attr_set[16] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
     bool res_dead = false;     // a resident kernel did not come back even after the abort word: the stream (and the handle) cannot be used any more
     uint32_t res_probed_w = 0;     // several ranks: the grid size the probe launch has found resident together with the peers' (0: not yet)
     unsigned long long res_probe_id = 0;
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_announce = 1;     // option announce (ResParams::announce)
+    int res_refill = 0;       // option refill: the streaming workgroups' form -- 1 first (hg_resident.hip.h: fused multiply-adds), 2 second (hg_streamer2.hip.h: integer matrix products), 0 auto
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
     unsigned char* res_acc = nullptr; // Gram + raw-dot accumulators, batch counters
@@ -1233,6 +1234,9 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "early_advance")) {
         if (value < 0 || value > 255) return fail("early_advance must be in [0,255]");
         h->res_early = (int)value;
+    } else if (!std::strcmp(name, "refill")) {
+        if (value < 0 || value > 2) return fail("refill must be 0 (auto), 1 (fused multiply-adds) or 2 (integer matrix products)");
+        h->res_refill = (int)value;
     } else if (!std::strcmp(name, "announce")) {
         h->res_announce = value != 0;
     } else if (!std::strcmp(name, "res_tune")) {
@@ -1346,17 +1350,39 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     return nullptr;
 }
 
+// the streaming workgroups' form of this handle's resident sweeps (option refill; env HGIBBS_REFILL for handles that do not set it)
+static int resident_refill(const hgibbs_ctx* h)
+{
+    static const int env_refill = std::getenv("HGIBBS_REFILL") ? std::atoi(std::getenv("HGIBBS_REFILL")) : 0;
+    const int want = h->res_refill ? h->res_refill : env_refill;
+    if (want == 0 && h->res_pivots) return 1; // (predicted pivots -- off by default -- take their Gram terms in the first form's refill only)
+    return want == 1 ? 1 : 2;
+}
+static size_t resident_streamer_lds(const hgibbs_ctx* h, const ResPlan& pl)
+{
+    if (resident_refill(h) == 2) return rl_streamer_lds(pl.B, pl.T);
+    return h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T);
+}
+
 // the resident kernel of a plan (T tiles per workgroup, stage clocks, missing-call build), with its LDS opt-in made on this handle's device
 static int resident_kernel(hgibbs_ctx* h, const ResPlan& pl, void (**out)(ResParams, const ResParams*))
 {
     void (*kern)(ResParams, const ResParams*) = nullptr;
     const bool dbg = h->debug_timing;
     const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
-    switch (pl.T) {
-    case 1: kern = miss ? (dbg ? k_sweep_resident<1, 1, 1> : k_sweep_resident<1, 0, 1>) : (dbg ? k_sweep_resident<1, 1, 0> : k_sweep_resident<1, 0, 0>); break;
-    default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
+    const bool limb = resident_refill(h) == 2;
+    if (limb) {
+        switch (pl.T) {
+        case 1: kern = miss ? (dbg ? k_sweep_limb<1, 1, 1> : k_sweep_limb<1, 0, 1>) : (dbg ? k_sweep_limb<1, 1, 0> : k_sweep_limb<1, 0, 0>); break;
+        default: kern = miss ? (dbg ? k_sweep_limb<2, 1, 1> : k_sweep_limb<2, 0, 1>) : (dbg ? k_sweep_limb<2, 1, 0> : k_sweep_limb<2, 0, 0>); break;
+        }
+    } else {
+        switch (pl.T) {
+        case 1: kern = miss ? (dbg ? k_sweep_resident<1, 1, 1> : k_sweep_resident<1, 0, 1>) : (dbg ? k_sweep_resident<1, 1, 0> : k_sweep_resident<1, 0, 0>); break;
+        default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
+        }
     }
-    const int ai = (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
+    const int ai = (limb ? 8 : 0) + (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
     if (!h->res_attr_set[ai]) { // (per handle: the attribute belongs to the function ON A DEVICE)
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->res_attr_set[ai] = true;
@@ -1385,7 +1411,7 @@ static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
     p.sweep_id = ++h->res_probe_id; // (the ranks probe alike: the handshake's words of an earlier probe never match)
-    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), std::max(rs_walker_lds(pl.B), rs_walker2_lds(pl.B)));
+    const size_t lds = std::max(resident_streamer_lds(h, pl), std::max(rs_walker_lds(pl.B), rs_walker2_lds(pl.B)));
     if (hipMemsetAsync(h->res_progress, 0, 16 * sizeof(unsigned long long), h->stream) != hipSuccess || hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream) != hipSuccess) return 1;
     kern<<<dim3(pl.W + 1), RS_BLOCK, lds, h->stream>>>(p, h->res_params);
     if (hipGetLastError() != hipSuccess) return 1;
@@ -1467,7 +1493,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8); // the grid's workgroups start within microseconds of each other -- or not at all
     p.dbg = h->debug_timing ? 1 : 0;
-    p.pivots = (h->nranks > 1 || h->any_missing) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
+    p.pivots = (h->nranks > 1 || h->any_missing || resident_refill(h) == 2) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
@@ -1500,7 +1526,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     HIP_TRY(hipMemsetAsync(h->res_acc, 0, RES_ACC_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->res_msg, 0, RS_MSG * sizeof(ResMsg), h->stream));
     HIP_TRY(hipMemsetAsync(h->res_state, 0, sizeof(ResState), h->stream));
-    const size_t lds = std::max(h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T), p.walker == 2 ? rs_walker2_lds(pl.B) : rs_walker_lds(pl.B));
+    const size_t lds = std::max(resident_streamer_lds(h, pl), p.walker == 2 ? rs_walker2_lds(pl.B) : rs_walker_lds(pl.B));
     void (*kern)(ResParams, const ResParams*) = nullptr;
     if (resident_kernel(h, pl, &kern)) return 1;
     {
