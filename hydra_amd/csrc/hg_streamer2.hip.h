@@ -7,14 +7,14 @@
 //
 // Here a wave owns a SLICE of the individuals (128 T of them: wave w the dwords [8 T w, 8 T (w + 1)) of the workgroup's 64 T) and takes
 // ALL columns against it, sixteen at a time, on v_mfma_i32_16x16x64_i8:
-//   A (16 columns x 64 individuals, bytes): lane (c, g) expands ONE dword of column c -- sixteen 2-bit codes of k-group g -- to sixteen
-//     bytes (seven instructions; codes 0 1 2, a missing call 3);
-//   B (64 individuals x 16 "columns"): eps as a fixed-point integer, round(eps 2^44), written in seven SIGNED base-256 digits; lane (j, g)
-//     holds digit j of the same sixteen individuals (lanes j >= 7: zero).  The digits are made once per update of eps, by the lanes that
+//   A (16 "rows" x 64 individuals, bytes): eps as a fixed-point integer, round(eps 2^44), written in seven SIGNED base-256 digits; lane (j, g)
+//     holds digit j of sixteen individuals of k-group g (lanes j >= 7: zero).  The digits are made once per update of eps, by the lanes that
 //     own the individuals (2 T each), and handed to the lanes that need them through a small LDS image per wave;
-//   D (i32): lane (j, g), register r: sum over the 64 individuals of code x digit j, column 4 g + r -- exact; sum_j D_j 256^j is the
-//     column's dot against the wave's slice as an integer of units 2^-44, exact again, and the eight waves' parts meet in one 8-byte
-//     LDS accumulator per position (integer adds: no order to keep).
+//   B (64 individuals x 16 columns): lane (c, g) expands ONE dword of column c -- the sixteen 2-bit codes of the same individuals -- to
+//     sixteen bytes (seven instructions; codes 0 1 2, a missing call 3);
+//   D (i32): lane (c, g), register r: sum over the 64 individuals of digit 4 g + r x code, column c -- exact; sum_j D_j 256^j is the
+//     column's dot against the wave's slice as an integer of units 2^-44, exact again: the lane puts its four digits together and the
+//     parts meet in one 8-byte LDS accumulator per position (integer adds: no order to keep).
 // One step (16 columns x 64 individuals) costs seven vector instructions and one MFMA instead of 48; eps is 2 T doubles per lane instead
 // of 16 T, so the update a8 (src/BayesRRm.cpp:1976-2010) costs an eighth; nothing is summed in floating point, so the dot does not
 // depend on which wave took what.  What the walker sees is unchanged: the workgroup's part of s1 as a fixed-point integer of 1 / fx_scale
@@ -475,7 +475,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
 #pragma unroll
                         for (int d = 0; d < ND; ++d) {
                             const rl_v4i z = rl_expand16(w[d]);
-                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z, bop[d], a1, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bop[d], z, a1, 0, 0, 0);
                             if constexpr (MISS) {
                                 if (anym) { // wave-uniform
                                     rl_v4i zm;
@@ -483,7 +483,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                                     zm.y = z.y & (z.y >> 1);
                                     zm.z = z.z & (z.z >> 1);
                                     zm.w = z.w & (z.w >> 1);
-                                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(zm, bop[d], a2, 0, 0, 0);
+                                    a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bop[d], zm, a2, 0, 0, 0);
                                 }
                                 const uint32_t hi1 = (w[d] >> 1) & 0x55555555u, mm = w[d] & hi1;
                                 xf[d] = (w[d] | hi1) ^ mm; // the x form 00 / 01 / 11, a missing call the free code 10
@@ -497,31 +497,22 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                             else *reinterpret_cast<uint2*>(rp) = make_uint2(xf[0], xf[1]);
                             if (wave == 0 && gl < 2u) reinterpret_cast<double*>(meta + (pc & bmask))[gl] = __hiloint2double(mhi, mlo);
                         }
-                        // lane (j, g) register rr: digit j of column 4 g + rr over the wave's slice.  The seven digits meet in lane j = 0 of the
-                        // row -- pairs in 32 bits first (|S| < 2^17), then two 64-bit steps -- and ONE lane per column adds the wave's part to the
-                        // position's accumulator (integer adds in LDS: the eight waves in any order; seven lanes a column would queue at the address)
-                        auto dpp64 = [](long long v, auto ctrl) {
-                            const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, decltype(ctrl)::value, 0xF, 0xF, true);
-                            const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)v >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
-                            return (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+                        // lane (c, g) register rr: digit 4 g + rr of column c over the wave's slice (the digits are the product's ROWS): the lane
+                        // puts its four digits together -- d0 + 2^8 d1 + 2^16 d2 + 2^24 d3, times 2^32 in k-group 1 (digits 4 .. 6; groups 2 and 3
+                        // hold zeros) -- and adds them to the position's accumulator: ONE instruction per group of sixteen columns, two lanes a column
+                        // (integer adds in LDS: the eight waves in any order)
+                        auto digits_sum = [&](const rl_v4i& a) {
+                            const int t01 = a[0] + (a[1] << 8), t23 = a[2] + (a[3] << 8); // (|digit sum| < 2^17: 25 bits each)
+                            return ((long long)t01 + ((long long)t23 << 16)) << (32u * (gl & 1u));
                         };
-                        auto digits_sum = [&](int S) {
-                            const int t = S + (__builtin_amdgcn_update_dpp(0, S, 0xB1, 0xF, 0xF, true) << 8); // even j: S_j + 256 S_(j+1)  (quad_perm [1,0,3,2])
-                            long long v = (long long)t << (8u * (cl & 6u));
-                            v += dpp64(v, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]: j = 0 takes j = 2, j = 4 takes j = 6
-                            v += dpp64(v, std::integral_constant<int, 0x104>{}); // row_shl:4: j = 0 takes j = 4
-                            return v;
-                        };
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const uint32_t pr = 16u * G + 4u * gl + (uint32_t)rr;
-                            const bool on = cl == 0u && pr >= Sx && pr < Sn;
-                            const long long v = digits_sum(a1[rr]);
-                            if (on) asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(acc1 + (pr - Sx))), "v"(v) : "memory");
+                        {
+                            const bool on = mine && gl < 2u;
+                            const long long v = digits_sum(a1);
+                            if (on) asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(acc1 + (pc - Sx))), "v"(v) : "memory");
                             if constexpr (MISS) {
                                 if (anym) { // wave-uniform
-                                    const long long v2 = digits_sum(a2[rr]);
-                                    if (on && v2) asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(acc2 + (pr - Sx))), "v"(v2) : "memory");
+                                    const long long v2 = digits_sum(a2);
+                                    if (on && v2) asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(acc2 + (pc - Sx))), "v"(v2) : "memory");
                                 }
                             }
                         }
