@@ -55,10 +55,14 @@ def algorithmic_bytes_bw(n, M, nnz, nshift):
     return M * (col + 8 * n) + nnz * 24 * n
 
 
-def valu_floor_ms(n, M, clock_hz=2.4e9, simds=1024):
-    """The least time one sweep's arithmetic can take on this design: three vector instructions per genotype-lane (extract, convert,
-    multiply-add), one instruction per SIMD per four clocks."""
-    return 3.0 * n * M / 64.0 * 4.0 / simds / clock_hz * 1e3
+def valu_floor_ms(n, M, refill=2, clock_hz=2.4e9, simds=1024):
+    """The least time one sweep's decoding arithmetic can take on this design, one vector instruction per SIMD per four clocks
+    (tools/ubench/valu_rate.hip measures 4.2-4.4).  First form of the streaming workgroups (refill = 1): three vector instructions per
+    genotype-lane (extract, convert, multiply-add).  Second form (refill = 2, hg_streamer2.hip.h): a dword of sixteen genotypes costs a
+    lane seven instructions to expand into an MFMA operand and two for the window's code form -- 9/16 of an instruction per genotype-lane
+    (the matrix product itself runs beside them: 4 x 16 x 16 x 64 byte products per instruction)."""
+    per_lane = 3.0 if refill == 1 else 9.0 / 16.0
+    return per_lane * n * M / 64.0 * 4.0 / simds / clock_hz * 1e3
 
 
 def committed_profile(kind, N, M, world, kernel="k_sweep_batch", missing=0.0):
@@ -590,7 +594,8 @@ def main():
             launches = enqueued
         kernel_ms_avg = sweep_ms / max(1, launches)
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
-        kname = "k_sweep_resident" if resident else "k_sweep_batch"
+        refill = int(stats[-1][0].get("refill", 0))
+        kname = ("k_sweep_limb" if refill == 2 else "k_sweep_resident") if resident else "k_sweep_batch"
         traffic, traffic_src = committed_profile("traffic", N, M, world, kname, args.missing)
         valu, valu_src = committed_profile("valu", N, M, world, kname, args.missing)
         anatomy = anatomy_all  # measured by every rank together (below the timed region), reported by rank 0
@@ -610,11 +615,12 @@ def main():
                 "hbm_frac_measured": (traffic["traffic_bytes_per_launch"] / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "valu_issue_frac_whole_launch": valu["valu_issue_frac"] if valu else None,
                 "valu_source": valu_src,
-                # what bounds the design: every genotype is decoded and multiplied -- field extract, int -> f64, fused multiply-add: three
-                # wave-instructions per 64 genotypes at least, and a SIMD issues ONE vector instruction per four clocks however many waves it
-                # holds (tools/ubench/valu_rate.hip measures 4.2-4.4): N x M x 3 / 64 x 4 clocks over the chip's 1024 SIMDs
-                "valu_floor_ms": valu_floor_ms(n_local, M),
-                "frac_of_valu_floor": valu_floor_ms(n_local, M) / (sweep_ms / K) if sweep_ms > 0 else None,
+                # what the decoding arithmetic costs at the very least (valu_floor_ms above): a SIMD issues ONE vector instruction per four
+                # clocks however many waves it holds.  The first form of the refill (3 instructions per genotype-lane) was bound by it; the
+                # second (integer matrix products, 9/16 of an instruction) is not -- the chain of rounds is
+                "valu_floor_ms": valu_floor_ms(n_local, M, refill),
+                "frac_of_valu_floor": valu_floor_ms(n_local, M, refill) / (sweep_ms / K) if sweep_ms > 0 else None,
+                "refill_form": refill,
                 "working_launches_per_iter": launches / K, "enqueued_launches_per_iter": enqueued / K,
                 "accepted_per_launch": accepted / max(1, launches),
                 "columns_streamed_per_accepted": streamed / max(1, accepted),

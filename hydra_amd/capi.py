@@ -41,7 +41,7 @@ class SweepStats(C.Structure):
                 ("accepted_markers", C.c_uint64), ("streamed_columns", C.c_uint64), ("tiles_per_workgroup_min", C.c_uint32),
                 ("tiles_per_workgroup_max", C.c_uint32), ("engine", C.c_uint32), ("walker", C.c_uint32), ("eps_sum_drift", C.c_double),
                 ("rounds", C.c_uint64), ("events", C.c_uint64), ("advances", C.c_uint64), ("chunks", C.c_uint64), ("refolds", C.c_uint64), ("pivots", C.c_uint64), ("predicted", C.c_uint64), ("shader_mhz", C.c_double),
-                ("ticks", C.c_uint64 * 16)]
+                ("ticks", C.c_uint64 * 16), ("refill", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class RestartState(C.Structure):
@@ -391,7 +391,7 @@ class Device:
                 "kernel_ms_avg": s.kernel_ms_avg, "carried_columns": s.carried_columns, "working_launches": s.working_launches,
                 "accepted_markers": s.accepted_markers, "streamed_columns": s.streamed_columns,
                 "tiles_per_workgroup_min": s.tiles_per_workgroup_min, "tiles_per_workgroup_max": s.tiles_per_workgroup_max,
-                "engine": s.engine, "walker": s.walker, "eps_sum_drift": s.eps_sum_drift, "rounds": s.rounds, "events": s.events,
+                "engine": s.engine, "walker": s.walker, "refill": s.refill, "eps_sum_drift": s.eps_sum_drift, "rounds": s.rounds, "events": s.events,
                 "advances": s.advances, "chunks": s.chunks, "refolds": s.refolds, "pivots": s.pivots, "predicted": s.predicted, "shader_mhz": s.shader_mhz, "ticks": list(s.ticks)}
 
 

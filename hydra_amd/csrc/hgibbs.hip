@@ -161,6 +161,7 @@ struct hgibbs_ctx {
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_announce = 1;     // option announce (ResParams::announce)
+    double eps_abs_bound = 0.0; // (sum of eps^8)^(1/8) >= max |eps| as of the last reduce_eps_all
     int res_refill = 0;       // option refill: the streaming workgroups' form -- 1 first (hg_resident.hip.h: fused multiply-adds), 2 second (hg_streamer2.hip.h: integer matrix products), 0 auto
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
     int res_pivots = 0;       // option pivots: Gram terms with predicted pivots at streaming time (no round trip for those events)
@@ -461,35 +462,43 @@ __global__ void k_add_scalar(double* eps, double c, uint32_t n_local, uint32_t n
     eps[p] = eps[p] + c;
 }
 
-// per-block partial (sum, sqn) in natural individual order inside the block
+// per-block partial (sum, sqn, sum of eps^8) in natural individual order inside the block
+// (the third: max |eps| <= (sum eps^8)^(1/8) -- how the host knows that every residual is inside the range of the streaming workgroups'
+// digits, hg_streamer2.hip.h, without a reduction of its own)
 __global__ __launch_bounds__(BLOCK) void k_reduce_eps(const double* __restrict__ eps, uint32_t n_pad, double* partial)
 {
-    __shared__ double sh[2][BLOCK_WAVES];
+    __shared__ double sh[3][BLOCK_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * BLOCK_WAVES + wave;
     double e[IPT];
     load_eps16(eps, tile, lane, e);
-    double s = 0.0, q = 0.0;
+    double s = 0.0, q = 0.0, o = 0.0;
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
+        const double e2 = e[i] * e[i], e4 = e2 * e2;
         s += e[i];
-        q += e[i] * e[i];
+        q += e2;
+        o += e4 * e4;
     }
     s = wave_sum(s);
     q = wave_sum(q);
+    o = wave_sum(o);
     if (lane == 0) {
         sh[0][wave] = s;
         sh[1][wave] = q;
+        sh[2][wave] = o;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double ts = 0.0, tq = 0.0;
+        double ts = 0.0, tq = 0.0, to = 0.0;
         for (int w = 0; w < BLOCK_WAVES; ++w) {
             ts += sh[0][w];
             tq += sh[1][w];
+            to += sh[2][w];
         }
-        partial[2 * blockIdx.x] = ts;
-        partial[2 * blockIdx.x + 1] = tq;
+        partial[3 * blockIdx.x] = ts;
+        partial[3 * blockIdx.x + 1] = tq;
+        partial[3 * blockIdx.x + 2] = to;
     }
 }
 
@@ -1001,13 +1010,14 @@ static int reduce_eps_all(hgibbs_ctx* h, double out[2])
 {
     const uint32_t nblk = h->n_pad / BLOCK_IND;
     k_reduce_eps<<<nblk, BLOCK, 0, h->stream>>>(h->eps[h->eps_cur], h->n_pad, h->scratch);
-    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 2, h->sums);
+    k_final_sum<<<1, BLOCK, 0, h->stream>>>(h->scratch, nblk, 3, h->sums);
     HIP_TRY(hipGetLastError());
-    if (bulk_allreduce(h, h->sums, 2, 0)) return 1;
-    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (bulk_allreduce(h, h->sums, 3, 0)) return 1;
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->sums, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     out[0] = h->scratch_host[0];
     out[1] = h->scratch_host[1];
+    h->eps_abs_bound = std::pow(std::max(h->scratch_host[2], 0.0), 0.125); // >= max |eps| over all ranks (not finite: no bound)
     return 0;
 }
 
@@ -1356,6 +1366,10 @@ static int resident_refill(const hgibbs_ctx* h)
     static const int env_refill = std::getenv("HGIBBS_REFILL") ? std::atoi(std::getenv("HGIBBS_REFILL")) : 0;
     const int want = h->res_refill ? h->res_refill : env_refill;
     if (want == 0 && h->res_pivots) return 1; // (predicted pivots -- off by default -- take their Gram terms in the first form's refill only)
+    // the second form holds eps as round(eps 2^44) in seven signed digits: |eps| < 64 (RL_EX, hg_streamer2.hip.h).  Left to itself the
+    // library takes the first form for a sweep that starts with a residual beyond 32 (or with no bound at all); asked for by option, the
+    // kernel's own check refuses such a sweep (error 5)
+    if (want == 0 && !(h->eps_abs_bound < 32.0)) return 1;
     return want == 1 ? 1 : 2;
 }
 static size_t resident_streamer_lds(const hgibbs_ctx* h, const ResPlan& pl)
@@ -1624,6 +1638,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.tiles_per_workgroup_min = s.tiles_per_workgroup_max = (uint32_t)pl.T;
     s.engine = 2;
     s.walker = (uint32_t)p.walker;
+    s.refill = (uint32_t)resident_refill(h);
     s.rounds = st.rounds;
     s.events = st.events;
     s.advances = st.advances;

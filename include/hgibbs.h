@@ -189,12 +189,15 @@ typedef struct {
     /* resident engine: rounds of the walker (= working_launches), events (messages that carried an update), rounds that only
      * advanced the window, posterior chunks evaluated, chunks that had to wait for dots streamed behind the last message */
     uint64_t rounds, events, advances, chunks, refolds;
-    uint64_t pivots;          /* resident engine: events that needed no round trip (predicted pivots whose Gram terms came with the columns) */
+    uint64_t pivots;          /* resident engine: events whose Gram terms were under way before the draw (announced: option announce) or came with the columns (option pivots) */
     uint64_t predicted;       /* resident engine, the census of why rounds end: events at markers whose effect was non-zero at sweep start
                                * (certain to change); events - predicted came unannounced; advances = rounds that ran out of window */
     double shader_mhz;        /* resident engine: s_memtime ticks per microsecond over the sweep (the clock the walker's compute unit held) */
     uint64_t ticks[16];       /* resident engine with option debug_timing: 100 MHz ticks, walker [0] fold [1] collect [2] evaluate
                                * [3] scan + draw [4] message + results + prefetch; streaming workgroup 0: [8] wait [9] update [10] Gram [11] stream */
+    uint32_t refill;          /* resident engine: the streaming workgroups' form -- 1 = fused multiply-adds per individual (hg_resident.hip.h),
+                               * 2 = integer matrix products over signed base-256 digits of eps (hg_streamer2.hip.h; option refill) */
+    uint32_t reserved_;
 } hgibbs_sweep_stats;
 int hgibbs_last_sweep_stats(hgibbs_t h, hgibbs_sweep_stats* out);
 /* measured streaming ceiling of this GPU: device-to-device copy of `bytes` (choose well above the 256 MB

@@ -27,7 +27,8 @@ def make_case(M, N, seed=7, causal_frac=0.05, missing_rate=0.0, missing_cols=1.0
     return synth.pack_bed_columns(geno), y
 
 
-def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None, missing_rate=0.0, missing_cols=1.0, expect_walker=None):
+def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1222, causal_frac=0.05, expect_T=None, missing_rate=0.0, missing_cols=1.0, expect_walker=None,
+                  expect_refill=None):
     bed, y = make_case(M, N, seed=M + N, causal_frac=causal_frac, missing_rate=missing_rate, missing_cols=missing_cols)
     ref = orc.Chain(oracle, bed, N, y, groups=groups, mS=mS, seed=seed, shuffle=1)
     dev = capi.Device(0)
@@ -45,6 +46,8 @@ def run_vs_oracle(oracle, M, N, iters=3, groups=None, mS=None, opts=None, seed=1
         assert ss["engine"] == 2 and ss["launches"] == 1 and ss["accepted_markers"] == M
         if expect_walker:
             assert ss["walker"] == expect_walker
+        if expect_refill:
+            assert ss["refill"] == expect_refill
         if expect_T:
             assert ss["tiles_per_workgroup_max"] == expect_T
         assert np.array_equal(ch.order(), ref.arr("order")), "marker order diverged at it %d" % it
@@ -75,10 +78,13 @@ def test_window_sizes(oracle, window):
     run_vs_oracle(oracle, 500, 3000, opts={"window": window})
 
 
+@pytest.mark.parametrize("refill", [1, 2])
 @pytest.mark.parametrize("cus,T", [(9, 1), (7, 2), (5, 2)])
-def test_tiles_per_workgroup(oracle, cus, T):
-    # N = 8000 -> 8 wave tiles: res_cus decides how many tiles one workgroup holds in registers
-    run_vs_oracle(oracle, 400, 8000, opts={"res_cus": cus}, expect_T=T)
+def test_tiles_per_workgroup(oracle, cus, T, refill):
+    # N = 8000 -> 8 wave tiles: res_cus decides how many tiles one workgroup holds in registers.  Both forms of the streaming workgroups:
+    # 1 = every wave whole columns, fused multiply-adds per individual; 2 (the default) = every wave a slice of the individuals, integer
+    # matrix products over eps's signed base-256 digits (hg_streamer2.hip.h)
+    run_vs_oracle(oracle, 400, 8000, opts={"res_cus": cus, "refill": refill}, expect_T=T, expect_refill=refill)
 
 
 def test_many_workgroups_multishard(oracle):
@@ -165,11 +171,43 @@ def test_predicted_pivots_many_workgroups(oracle):
     assert dev.sweep_stats()["pivots"] > 0
 
 
+@pytest.mark.parametrize("refill", [1, 2])
 @pytest.mark.parametrize("N,rate,cols", [(1024, 0.02, 1.0), (4099, 0.01, 1.0), (9001, 0.05, 0.3), (20011, 0.01, 1.0)])
-def test_missing_calls(oracle, N, rate, cols):
+def test_missing_calls(oracle, N, rate, cols, refill):
     """Columns with missing calls (the build that keeps s2 = sum of eps over a column's calls per column and takes the four-term
-    Gram sums A, B, C, D of src/BayesRRm.cpp:1785-1790's algebra): in every column, or in a share of them next to clean ones."""
-    run_vs_oracle(oracle, 400, N, iters=4, missing_rate=rate, missing_cols=cols)
+    Gram sums A, B, C, D of src/BayesRRm.cpp:1785-1790's algebra): in every column, or in a share of them next to clean ones.
+    Both forms of the streaming workgroups (the second takes R = sum of eps over the missing calls as a second matrix product)."""
+    run_vs_oracle(oracle, 400, N, iters=4, missing_rate=rate, missing_cols=cols, opts={"refill": refill}, expect_refill=refill)
+
+
+def test_a_residual_beyond_the_digits_range(oracle):
+    """The second form of the streaming workgroups holds eps as round(eps 2^44) in seven signed base-256 digits: |eps| < 64 is required
+    (standardised phenotypes stay within a few units).  Left to itself the library sees the outlier in its pre-sweep reduction (the sum of
+    eps^8 bounds max |eps|) and takes the first form, with the oracle's chain; asked for the second form by option, the kernel refuses
+    the sweep with error 5 -- never a wrapped sum."""
+    M, N = 200, 9001
+    bed, y = make_case(M, N, seed=5)
+    y = y.copy()
+    y[7] += 1e6 * np.std(y)  # one outlier: ~ sqrt(N - 1) = 95 standard deviations after the phenotype is standardised
+    ref = orc.Chain(oracle, bed, N, y, seed=1222, shuffle=1)
+    dev = capi.Device(0)
+    dev.load_bed(bed, N)
+    dev.set_option("engine", 2)
+    ch = capi.Chain(dev, y, seed=1222, shuffle=1)
+    assert np.abs(dev.get_residual()).max() > 64.0
+    for _ in range(2):
+        ref.iterate()
+        ch.iterate()
+        assert dev.sweep_stats()["refill"] == 1
+        beta, comp, _ = dev.get_beta()
+        assert np.array_equal(comp, ref.arr("components")) and close(beta, ref.arr("beta"))
+    dev2 = capi.Device(0)
+    dev2.load_bed(bed, N)
+    dev2.set_option("engine", 2)
+    dev2.set_option("refill", 2)
+    ch2 = capi.Chain(dev2, y, seed=1222, shuffle=1)
+    with pytest.raises(capi.HgError, match="abort code 5"):
+        ch2.iterate()
 
 
 def test_missing_calls_small_window_and_two_tiles(oracle):

@@ -1,8 +1,9 @@
 // The refill's dot products as ONE integer matrix product ("limb dots"): sixteen columns of 2-bit codes against
 // eps held as a fixed-point integer of seven signed 8-bit digits, on v_mfma_i32_16x16x64_i8 -- exact, and a fraction of the vector
 // instructions of the per-individual convert + fused multiply-add form.  This program checks the operand maps the kernel relies on with
-// random data against the host's integer sums (A: lane (c, g) = column c, sixteen individuals of k-group g; B: lane (j, g) = digit j of
-// the SAME sixteen individuals; D: lane (j, g) register r = column 4 g + r, digit j) and times the inner step.
+// random data against the host's integer sums (A: lane (j, g) = digit j of sixteen individuals of k-group g; B: lane (c, g) = column c, the
+// codes of the SAME sixteen individuals; D: lane (c, g) register r = digit 4 g + r of column c -- a lane puts its four digits together
+// itself) and times the inner step.
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_limb_dot mfma_limb_dot.hip ; run: ./mfma_limb_dot
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -34,12 +35,12 @@ __global__ void k_dot(const uint32_t* codes, const v4i* digits, long long* out, 
     v4i b[STEPS];
     for (int s = 0; s < STEPS; ++s) {
         x[s] = codes[(c * STEPS + s) * 4 + g];
-        b[s] = digits[(s * 4 + g) * 16 + c];
+        b[s] = digits[(s * 4 + g) * 16 + c]; // (as the A operand: lane (j = c, g))
     }
     const unsigned long long t0 = wall_clock64();
     for (int r = 0; r < reps; ++r) {
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(expand16(x[s]), b[s], acc, 0, 0, 0);
+        for (int s = 0; s < STEPS; ++s) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[s], expand16(x[s]), acc, 0, 0, 0);
         if (r + 1 < reps) { // (keep the loop honest: the codes change, the sum of the last pass is what is checked)
             acc = v4i{0, 0, 0, 0};
 #pragma unroll
@@ -47,15 +48,13 @@ __global__ void k_dot(const uint32_t* codes, const v4i* digits, long long* out, 
         }
     }
     const unsigned long long t1 = wall_clock64();
-    // digit j of columns 4 g + r, r = 0 .. 3: the 64-bit value S_j 256^j, summed over the eight lanes j = 0 .. 7 of the row
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int S = (c < 7) ? acc[r] : 0;
-        long long v = (long long)S << (8 * (c & 7));
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        if (c == 0) out[4 * g + r] = v;
+    // lane (c, g): digits 4 g .. 4 g + 3 of column c: d0 + 2^8 d1 + 2^16 d2 + 2^24 d3, times 2^32 in k-group 1 (groups 2, 3: zeros)
+    {
+        const int t01 = acc[0] + (acc[1] << 8), t23 = acc[2] + (acc[3] << 8);
+        long long v = ((long long)t01 + ((long long)t23 << 16)) << (32 * (g & 1));
+        if (g >= 2) v = 0;
+        v += __shfl_xor(v, 16, 64);
+        if (g == 0) out[c] = v;
     }
     if (lane == 0) clocks[0] = t1 - t0;
 }
