@@ -153,8 +153,19 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
  *   res_cus         resident engine: compute units to use (0 = all; one of them walks the chain, the others stream)
  *   pivots          resident engine: 1 = take the Gram terms of markers whose effect is non-zero at sweep start when a column is
  *                   streamed (their events need no round trip); default 0 (measured slower on MI355X)
+ *   refill          resident engine, the streaming workgroups' form: 0 auto (default: 2, unless option pivots is on or the sweep starts
+ *                   with a residual beyond the digits' range, |eps| >= 32), 1 = every wave whole columns, three vector instructions per
+ *                   genotype (hg_resident.hip.h), 2 = every wave a slice of the individuals, the dots as integer matrix products over
+ *                   eps's signed base-256 digits (hg_streamer2.hip.h; needs |eps| < 64: a sweep that meets a larger one fails, error 5)
+ *   walker          resident engine: 0 auto (the second where it applies: every marker takes a uniform, <= 4 groups, one rank), 1 the
+ *                   first walker, 2 the second (hg_walker2.hip.h; the call fails where it does not apply)
+ *   announce        second walker: 1 (default) = an event that is certain (a marker whose effect is non-zero) is announced before
+ *                   its draw, so that its Gram terms travel meanwhile
+ *   early_advance   second walker: a walk that runs out of dots moves the window on at once when at least this many positions have
+ *                   passed (default 24; 0 = it waits)
  *   res_timeout_ms  resident engine: longest wait of any workgroup for another before the sweep is abandoned with an error
- *                   (default 2000); res_deadline_ms: the host's own deadline for the kernel (0 = derived from M)
+ *                   (default 2000); res_deadline_ms: the host's own deadline for the kernel (0 = derived from M, extended while the
+ *                   walker's round counter moves)
  *   batch           speculative batch width, 1..256 (0 auto)
  *   cols_per_group  batch columns per workgroup: 2, 4 (default), 8, 16
  *   slices          most tile-group slices per column group, 1..64 (0 auto)
@@ -207,9 +218,10 @@ int hgibbs_stream_ceiling(hgibbs_t h, uint64_t bytes, int reps, double* gbps);
  * debug_timing = 1 since the last call (which clears them): bench.py's launch anatomy, tools/dbg_times.py */
 int hgibbs_debug_times(hgibbs_t h, uint64_t* out48);
 /* diagnostic: wall-clock stamps (100 MHz) of the resident engine's last 4096 messages, taken by the build with option
- * debug_timing = 1: 8 rows of 4096 words indexed by message number mod 4096 -- walker: [0] message stored, [1] its Gram
- * terms collected, [2] next message decided, [3] positions it consumed; streaming workgroup 0: [4] message seen, [5] eps
- * updated, [6] Gram terms sent, [7] refill streamed (tools/res_anatomy.py) */
+ * debug_timing = 1: 10 rows of 4096 words indexed by message number mod 4096 (`words` <= 10 x 4096 are copied) -- walker: [0] message
+ * stored, [1] its Gram terms collected, [2] next message decided, [3] positions it consumed; streaming workgroup 0: [4] message seen
+ * (an announced event: the message proper, not its announcement), [5] eps updated, [6] Gram terms sent, [7] refill streamed; rows 8, 9:
+ * reserved for experiments (tools/res_anatomy.py reads the first eight) */
 int hgibbs_resident_trace(hgibbs_t h, uint64_t* out, uint64_t words);
 
 /* ======================================================================== */
