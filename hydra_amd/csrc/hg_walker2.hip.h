@@ -646,11 +646,14 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 const int g0 = w2_uni(ga_v & 0x0fffffff) * K;
                 const double prob = (double)mt_temper(word_v) * (1.0 / 4294967296.0);
                 // a5 (src/BayesRRm.cpp:1859-1921) over the lanes: lane x < K holds logL_x; lane 8 kk + l the term exp(logL_l - logL_kk)
-                double Lm = 0.0;
+                // (lane x also keeps num / denom_x and the draw's standard deviation of component x: the draw below takes the chosen component's
+                // from its lane -- the same quotient, not a second division and a second trip to LDS behind the walk)
+                double Lm = 0.0, mk = 0.0, sdl = 0.0;
                 {
                     const int lk = lane < K ? lane : 0;
                     const double den = sh.htab[g0 + lk], lpi = sh.htab[HT_LDS + g0 + lk], hlg = sh.htab[2 * HT_LDS + g0 + lk];
-                    const double mk = num / (lk ? den : 1.0);
+                    sdl = sh.htab[3 * HT_LDS + g0 + lk];
+                    mk = num / (lk ? den : 1.0);
                     Lm = lk ? lpi - hlg + mk * num * i_2sigE : lpi;
                 }
                 const int kk = lane >> 3, l = lane & 7;
@@ -686,10 +689,11 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 double bnew = 0.0;
                 uint32_t consumed = 0u, gerr = 0u;
                 if (k > 0) { // (uniform) a7: the new effect, on one lane
+                    const double mean_k = rs_readlane(mk, k), sd_k = rs_readlane(sdl, k);
                     if (lane == 0) {
                         RingGen g{sh.mt, upos + 1u == W2_RING ? 0u : upos + 1u, blk * (uint32_t)MT_N - (gpos + (qc - C) + 1u), 0u, 0u};
                         const ZigLds zt{sh.zig_nx, sh.zig_ny, zig_ex, zig_ey};
-                        bnew = norm_rng_sd(g, zt, num / sh.htab[g0 + k], sh.htab[3 * HT_LDS + g0 + k]);
+                        bnew = norm_rng_sd(g, zt, mean_k, sd_k);
                         consumed = g.n;
                         gerr = g.err;
                     }
