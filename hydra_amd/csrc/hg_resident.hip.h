@@ -423,6 +423,107 @@ __device__ __forceinline__ void fma_dword(uint32_t g, const double (&e)[IPT], do
 #undef HG_FD_OPERANDS
 }
 
+// The integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind the event column q, by one streaming workgroup (both forms:
+// the window's codes are [slot][64 T dwords] in either): wave w takes the columns [w Vw, (w + 1) Vw) of the V = Sx - (q + 1) behind q, all of
+// the workgroup's individuals, and sends its sums itself -- memory-side atomic adds, the arrival count in the word's top byte.  xq: the
+// lane's dwords of column q, mq: (mave, mstd) of q, nev: the event's number (its parity selects the accumulator row).
+template <int T, int MISS>
+__device__ __forceinline__ void rs_gram_terms(const ResParams& p, const uint32_t* ring, const double2* meta, uint32_t wg, int wave, int lane, uint32_t q, uint32_t Sx, uint32_t bmask,
+                                              uint32_t nev, const uint32_t (&xq)[T], const double2& mq)
+{
+    constexpr bool with_gram = true;
+    const uint32_t V = Sx - (q + 1u);
+    const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
+    if constexpr (MISS) {
+    if (V && with_gram) {
+        // Four sums where a call may be missing in either column (x_j'x_q = mstd_j mstd_q (A - m_q B - m_j C + m_j m_q D), sums over
+        // the individuals called in both): with the missing calls' fields cleared, A = sum g_j g_q as before, B = G_j - P,
+        // C = G_q - Q, D = N - nm_j - nm_q + X with P = sum of g_j over q's missing calls, Q = sum of g_q over j's, X = calls
+        // missing in both -- popcounts against the missing masks.  What depends on the individuals, A + m_q P + m_j Q + m_j m_q X
+        // (>= 0), is summed over the wave as a double and sent as ONE fixed-point word per column (units of 2^-RS_GFX, arrival
+        // count in the top byte); the walker adds the rest from the markers' counts.
+        GramPivot gp[T];
+        uint32_t xqc[T], mq1[T], mq2[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { // window code 10 = missing: its mask, and the x form with those fields cleared
+            mq1[t] = (xq[t] >> 1) & ~xq[t] & 0x55555555u;
+            mq2[t] = mq1[t] | (mq1[t] << 1);
+            xqc[t] = xq[t] & ~mq2[t];
+            gp[t] = gram_pivot_x(xqc[t]);
+        }
+        const double mqv = mq.x;
+        // the four integer sums of a column meet packed (A' | P' << 16, Q | X << 16: a lane adds at most 192 / 96 / 64 / 32, the wave
+        // 12288 / 6144 / 4096 / 2048), sixteen columns to a reduce-scatter: lane c < 16 then holds column c0 + c's totals, forms its
+        // term and sends it
+        for (uint32_t c0 = 0; c0 < Vw; c0 += 16u) { // wave-uniform
+            uint32_t ap[16], qx[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t i = i0 + c0 + (uint32_t)k;
+                const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
+                const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+                uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    // (the column's word is taken as it stands: its missing fields, code 10, count 1 in a popcount -- A' = A + Q and
+                    // P' = P + X -- and the integers are put right behind the wave sums: no cleared copy of the word is made)
+                    const uint32_t w = rp[t];
+                    const uint32_t mj1 = ~(w | 0xAAAAAAAAu) & (w >> 1), mj2 = mj1 | (mj1 << 1); // (one v_bfi_b32)
+                    A += gram16x(w, gp[t]);
+                    P += (uint32_t)__popc(w & mq2[t]);
+                    Q += (uint32_t)__popc(xqc[t] & mj2);
+                    X += (uint32_t)__popc(mj1 & mq1[t]);
+                }
+                ap[k] = A | (P << 16);
+                qx[k] = Q | (X << 16);
+            }
+            const uint32_t apt = wave_sum16_rows(ap, lane), qxt = wave_sum16_rows(qx, lane);
+            const uint32_t mycol = i0 + c0 + ((uint32_t)lane & 15u);
+            if ((uint32_t)lane < 16u && c0 + (uint32_t)lane < Vw && mycol < V) {
+                const double mj = meta[(q + 1u + mycol) & bmask].x;
+                const uint32_t Qs = qxt & 0xffffu, Xs = qxt >> 16, As = (apt & 0xffffu) - Qs, Ps = (apt >> 16) - Xs; // (A = A' - Q, P = P' - X: exact)
+                const double mine = ((double)As + mqv * (double)Ps) + (mj * (double)Qs + (mj * mqv) * (double)Xs);
+                const double MAGIC = 6755399441055744.0;
+                const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
+                __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + mycol) & bmask), RS_ONE64 | fx, HG_RLX_AGENT);
+            }
+        }
+    }
+    } else
+    if (V && with_gram) {
+    GramPivot gp[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) gp[t] = gram_pivot_x(xq[t]);
+    uint32_t acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0u;
+#pragma unroll
+    for (int cb = 0; cb < 32; cb += 8) {
+        if ((uint32_t)cb < Vw) { // wave-uniform; the eight columns of a group are read together (past the end: column V - 1 again, unused)
+            uint32_t wv[8][T];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t i = i0 + (uint32_t)(cb + c);
+                const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
+                const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
+#pragma unroll
+                for (int t = 0; t < T; ++t) wv[c][t] = rp[t];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uint32_t g = 0u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) g += gram16x(wv[c][t], gp[t]);
+                acc[(cb + c) >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
+            }
+        }
+    }
+    const uint32_t mine = wave_sum16_scatter(acc, lane); // lane c: the wave's Gram term of its column c
+    if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words (by window slot of the column, up to the wrap): count in the top byte
+        __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + i0 + (uint32_t)lane) & bmask), RS_ONE | mine, HG_RLX_AGENT);
+    }
+}
+
 template <int T, int DBG, int MISS>
 __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* smem)
 {
@@ -583,94 +684,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
 
             // ---- FIRST what the walker waits for (they need the window's codes only, not eps): the integer Gram terms A_jq = sum_i g_ij g_iq of the window columns behind q (their dots were taken before this
             // update): the walker corrects them, x_j'eps_new = x_j'eps_old + dbeta mstd_j mstd_q (A_jq - N mave_j mave_q) ----
-            const uint32_t V = Sx - (q + 1u);
-            const uint32_t Vw = (V + 7u) / 8u, i0 = (uint32_t)wave * Vw;
-            if constexpr (MISS) {
-            if (V && with_gram) {
-                // Four sums where a call may be missing in either column (x_j'x_q = mstd_j mstd_q (A - m_q B - m_j C + m_j m_q D), sums over
-                // the individuals called in both): with the missing calls' fields cleared, A = sum g_j g_q as before, B = G_j - P,
-                // C = G_q - Q, D = N - nm_j - nm_q + X with P = sum of g_j over q's missing calls, Q = sum of g_q over j's, X = calls
-                // missing in both -- popcounts against the missing masks.  What depends on the individuals, A + m_q P + m_j Q + m_j m_q X
-                // (>= 0), is summed over the wave as a double and sent as ONE fixed-point word per column (units of 2^-RS_GFX, arrival
-                // count in the top byte); the walker adds the rest from the markers' counts.
-                GramPivot gp[T];
-                uint32_t xqc[T], mq1[T], mq2[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) { // window code 10 = missing: its mask, and the x form with those fields cleared
-                    mq1[t] = (xq[t] >> 1) & ~xq[t] & 0x55555555u;
-                    mq2[t] = mq1[t] | (mq1[t] << 1);
-                    xqc[t] = xq[t] & ~mq2[t];
-                    gp[t] = gram_pivot_x(xqc[t]);
-                }
-                const double mqv = mq.x;
-                // the four integer sums of a column meet packed (A | P << 16, Q | X << 16: a lane adds at most 128 / 64 / 64 / 32, the wave
-                // 8192 / 4096 / 4096 / 2048), sixteen columns to a reduce-scatter: lane c < 16 then holds column c0 + c's totals, forms its
-                // term and sends it
-                for (uint32_t c0 = 0; c0 < Vw; c0 += 16u) { // wave-uniform
-                    uint32_t ap[16], qx[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t i = i0 + c0 + (uint32_t)k;
-                        const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
-                        const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-                        uint32_t A = 0u, P = 0u, Q = 0u, X = 0u;
-#pragma unroll
-                        for (int t = 0; t < T; ++t) {
-                            const uint32_t w = rp[t];
-                            const uint32_t mj1 = (w >> 1) & ~w & 0x55555555u, mj2 = mj1 | (mj1 << 1);
-                            const uint32_t xj = w & ~mj2;
-                            A += gram16x(xj, gp[t]);
-                            P += (uint32_t)__popc(xj & mq2[t]);
-                            Q += (uint32_t)__popc(xqc[t] & mj2);
-                            X += (uint32_t)__popc(mj1 & mq1[t]);
-                        }
-                        ap[k] = A | (P << 16);
-                        qx[k] = Q | (X << 16);
-                    }
-                    const uint32_t apt = wave_sum16_rows(ap, lane), qxt = wave_sum16_rows(qx, lane);
-                    const uint32_t mycol = i0 + c0 + ((uint32_t)lane & 15u);
-                    if ((uint32_t)lane < 16u && c0 + (uint32_t)lane < Vw && mycol < V) {
-                        const double mj = meta[(q + 1u + mycol) & bmask].x;
-                        const double mine = ((double)(apt & 0xffffu) + mqv * (double)(apt >> 16)) + (mj * (double)(qxt & 0xffffu) + (mj * mqv) * (double)(qxt >> 16));
-                        const double MAGIC = 6755399441055744.0;
-                        const unsigned long long fx = (unsigned long long)(__double_as_longlong(mine * (double)(1ull << RS_GFX) + MAGIC) - __double_as_longlong(MAGIC));
-                        __hip_atomic_fetch_add(p.gacc64 + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + mycol) & bmask), RS_ONE64 | fx, HG_RLX_AGENT);
-                    }
-                }
-            }
-            } else
-            if (V && with_gram) {
-            GramPivot gp[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) gp[t] = gram_pivot_x(xq[t]);
-            uint32_t acc[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0u;
-#pragma unroll
-            for (int cb = 0; cb < 32; cb += 8) {
-                if ((uint32_t)cb < Vw) { // wave-uniform; the eight columns of a group are read together (past the end: column V - 1 again, unused)
-                    uint32_t wv[8][T];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const uint32_t i = i0 + (uint32_t)(cb + c);
-                        const uint32_t slot = (q + 1u + (i < V ? i : V - 1u)) & bmask;
-                        const uint32_t* rp = ring + slot * 64u * T + (uint32_t)lane * T;
-#pragma unroll
-                        for (int t = 0; t < T; ++t) wv[c][t] = rp[t];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        uint32_t g = 0u;
-#pragma unroll
-                        for (int t = 0; t < T; ++t) g += gram16x(wv[c][t], gp[t]);
-                        acc[(cb + c) >> 1] += g << (16 * (c & 1)); // a lane adds at most 64 T <= 256 per column: the 64-lane sum fits 16 bits
-                    }
-                }
-            }
-            const uint32_t mine = wave_sum16_scatter(acc, lane); // lane c: the wave's Gram term of its column c
-            if ((uint32_t)lane < Vw && i0 + (uint32_t)lane < V) // one instruction per wave, contiguous words (by window slot of the column, up to the wrap): count in the top byte
-                __hip_atomic_fetch_add(p.gacc + ((size_t)(nev & 1u) * RS_NSH + (wg % p.nsh)) * RS_GROW + ((q + 1u + i0 + (uint32_t)lane) & bmask), RS_ONE | mine, HG_RLX_AGENT);
-            }
+            if (with_gram) rs_gram_terms<T, MISS>(p, ring, meta, wg, wave, lane, q, Sx, bmask, nev, xq, mq);
             if (with_gram) ++nev;
             lap(2);
             if (timing) p.trace[6 * RS_TRACE + seq % RS_TRACE] = wall_clock64();
