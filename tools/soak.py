@@ -21,6 +21,8 @@ MISSING = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 VARIANTS = [("plain: gram=0, batch 200", {"gram": 0, "batch": 200}),
             ("batch engine, defaults", {"engine": 1}),
             ("resident engine", {"engine": 2}),
+            ("resident engine, first form of the streaming workgroups", {"engine": 2, "refill": 1}),
+            ("resident engine, first walker, no announcements", {"engine": 2, "walker": 1}),
             ("resident engine, window 64, predicted pivots", {"engine": 2, "window": 64, "pivots": 1}),
             ("resident engine, window 128, 250 compute units", {"engine": 2, "window": 128, "res_cus": 250}),
             ("carry on, ahead 64", {"carry": 1, "ahead": 64}),
