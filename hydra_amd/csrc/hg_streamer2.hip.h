@@ -144,7 +144,6 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
     const uint32_t B = p.B, bmask = B - 1u, M = p.M;
     double* const tab1 = reinterpret_cast<double*>(smem);                               // the update's addends by window code (00, 01, 10 = missing, 11)
     unsigned long long* const lmsg = reinterpret_cast<unsigned long long*>(smem + 256); // the message, as the polling lane read it
-    uint32_t* const fin_cnt = reinterpret_cast<uint32_t*>(smem + 320);                  // waves of this round that are through their atomics
     unsigned long long* const tacc = reinterpret_cast<unsigned long long*>(smem + 384); // [8] stage clocks of the debug build
     double2* const meta = reinterpret_cast<double2*>(smem + rl_meta_off());             // (mave, mstd) of the window slots
     unsigned long long* const acc1 = reinterpret_cast<unsigned long long*>(smem + rl_acc_off(B));  // [position - Sx] this round's refill: the column's dot, integer units of 2^-44
@@ -152,7 +151,6 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
     unsigned char* const zero16 = smem + rl_zero_off(B);
     unsigned char* const dimg = smem + rl_digit_off(B) + (size_t)wave * (8 * T * RL_BLK); // this wave's digit image: [block of sixteen individuals][digit][16 bytes in A's order]
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + rl_ring_off(B, T));       // [B][64 * T] codes of the window columns (x form)
-    if (tid == 0) *fin_cnt = 0u;
     if (tid < 16) reinterpret_cast<uint32_t*>(zero16)[tid] = 0u;
     for (uint32_t i = (uint32_t)tid; i < 2u * B; i += RS_BLOCK) acc1[i] = 0ull; // (acc1 and acc2 are adjacent)
     const bool timing = DBG && wg == 0 && tid == 0;
@@ -245,6 +243,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
     uint32_t C = 0, Sx = 0, seq = 0, nev = 0;
     uint32_t kind = RS_ADVANCE, ncons = 0;
     bool gram_sent = false; // the Gram terms of the event the next message brings have been sent (on its announcement)
+    bool count_due = false; // (last wave) this round's adds are out, the batch counter's is not
     bool last = M == 0;
     double dbeta = 0.0;
     // Set r holds the group H_r of sixteen positions [16 H_r, 16 H_r + 16) -- the first group = r (mod RL_NG) that is not admitted to the
@@ -286,7 +285,11 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
             uint32_t npoll = 0;
             u4_t v;
             for (;;) {
-                v = rs_load16(m);
+                v = rs_load16(m); // (waits for everything this wave has in flight: the round's adds to the shard's accumulators have been performed)
+                if (count_due) {
+                    __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
+                    count_due = false;
+                }
                 if (v.y == seq && ((v.x >> 12) & 0xffffu) == rs_msg_check(seq, v.z, v.w) && !(announced && ((v.x >> 28) & 7u) == (uint32_t)RS_ANNOUNCE)) break;
                 if (wall_clock64() - t0 > p.timeout || ((++npoll & 255u) == 0u && __hip_atomic_load(p.progress + 2, HG_RLX_AGENT) != 0ull)) { // (or the host gave the sweep up)
                     v.x = (uint32_t)RS_ABORT << 28;
@@ -440,39 +443,34 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the window's new columns and this round's sums are in LDS for every wave
         lap(4);
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 2u;
-        // One thread per refilled position rounds the column's exact sum (units of 2^-44) to the fixed-point units the workgroups' parts
-        // travel in (1 / fx_scale: "x + 1.5 2^52", round to nearest) and adds it to the shard's accumulator; once the adds have been performed,
-        // one add to the shard's batch counter tells the walker that this workgroup's part is in (first form: the same protocol).
-        for (uint32_t t = (uint32_t)tid; t < nnew; t += RS_BLOCK) {
-            const double MAGIC = 6755399441055744.0;
-            const double unit = p.fx_scale * (1.0 / (double)(1ull << RL_EX));
-            const long long tot = (long long)acc1[t];
-            acc1[t] = 0ull; // (the next round's lanes add behind this round's last barrier)
-            if constexpr (MISS) {
-                const long long tot2 = (long long)acc2[t];
-                acc2[t] = 0ull;
-                const double xr = (double)tot2 * unit;
-                if (!(fabs(xr) < 2.2e15)) atomicMax(&p.state->error, 5u);
-                const long long fr = __double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC);
-                if (fr) __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr, HG_RLX_AGENT);
-            }
-            const double xs = (double)tot * unit;
-            if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range: the sweep is refused, not wrapped
-            const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
-            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
-        }
-        {
-            const uint32_t nf = (nnew + 63u) / 64u;
-            const uint32_t nfin = nf < 1u ? 1u : (nf > (uint32_t)RS_WAVES ? (uint32_t)RS_WAVES : nf);
-            if ((uint32_t)wave < nfin) {
-                wait_vmcnt<0>();
-                if (lane == 0) {
-                    const uint32_t got = __hip_atomic_fetch_add(fin_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
-                    if (got == nfin) {
-                        __hip_atomic_store(fin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
-                    }
+        // One lane per refilled position rounds the column's exact sum (units of 2^-44) to the fixed-point units the workgroups' parts travel
+        // in (1 / fx_scale: "x + 1.5 2^52", round to nearest) and adds it to the shard's accumulator; once the adds have been performed, one
+        // add to the shard's batch counter tells the walker that this workgroup's part is in (first form: the same protocol).  The LAST wave
+        // does it all -- it is the one that polls for the next message, and the wait of its first poll (vmcnt counts in order) is the wait
+        // for these adds: nobody stands at the barrier while atomics drain, the count goes out behind the first poll (take_message).
+        if (wave == RS_WAVES - 1) {
+            for (uint32_t t = (uint32_t)lane; t < nnew; t += WAVE) {
+                const double MAGIC = 6755399441055744.0;
+                const double unit = p.fx_scale * (1.0 / (double)(1ull << RL_EX));
+                const long long tot = (long long)acc1[t];
+                acc1[t] = 0ull; // (the next round's lanes add behind this round's last barrier)
+                if constexpr (MISS) {
+                    const long long tot2 = (long long)acc2[t];
+                    acc2[t] = 0ull;
+                    const double xr = (double)tot2 * unit;
+                    if (!(fabs(xr) < 2.2e15)) atomicMax(&p.state->error, 5u);
+                    const long long fr = __double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC);
+                    if (fr) __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr, HG_RLX_AGENT);
                 }
+                const double xs = (double)tot * unit;
+                if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range: the sweep is refused, not wrapped
+                const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
+                __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
+            }
+            count_due = true;
+            if (last) { // (no message follows: the count goes out here)
+                wait_vmcnt<0>();
+                if (lane == 0) __hip_atomic_fetch_add(p.rcnt + (size_t)(wg % p.rsh) * RS_CROW, 1u, HG_RLX_AGENT);
             }
         }
         lap(5);
