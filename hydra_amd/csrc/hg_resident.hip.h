@@ -225,6 +225,9 @@ static_assert(rs_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds
 // wait is placed by hand, once per pass (cols_landed); a set is read only behind it.  Set R = v(224 + R) for T = 1, v[224 + 2R : 225 + 2R]
 // for T = 2.  tools/asm_check_loads.py verifies on the emitted code that no other instruction names these registers.
 constexpr int RS_VGPR_LIMIT = 216; // v216 .. v220: the lanes' (mave, mstd, next id), v224 .. v255: the sets
+// (amdgpu_num_vgpr counts the unified VGPR + AGPR file of this target -- the compiler doubles the attribute's value: the kernels carry HALF
+// the limit, which caps the registers the compiler allocates itself at the limit; the named registers in the clobber lists of the inline
+// assembly keep the wave's allocation at 256.  Measured with a small kernel: amdgpu_num_vgpr(216) caps nothing, (108) caps at 216.)
 #define RS_SET_LIST(X) X(0, 224, 224, 225) X(1, 225, 226, 227) X(2, 226, 228, 229) X(3, 227, 230, 231) X(4, 228, 232, 233) X(5, 229, 234, 235) X(6, 230, 236, 237) X(7, 231, 238, 239) X(8, 232, 240, 241) X(9, 233, 242, 243) X(10, 234, 244, 245) X(11, 235, 246, 247) X(12, 236, 248, 249) X(13, 237, 250, 251) X(14, 238, 252, 253) X(15, 239, 254, 255)
 template <int T, int R>
 __device__ __forceinline__ void rs_set_load(uint32_t voff, const uint8_t* base)
@@ -2095,7 +2098,7 @@ __device__ __forceinline__ void rs_probe_peers(const ResParams& p)
 }
 
 template <int T, int DBG, int MISS>
-__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT))) void k_sweep_resident(ResParams p, const ResParams* pg)
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LIMIT / 2))) void k_sweep_resident(ResParams p, const ResParams* pg)
 {
     if (!rs_rendezvous(p, hg_smem)) return;
     if (p.M == 0xffffffffu) { // (a probe launch: is the grid resident at once, and together with the peers' -- hgibbs.hip, resident_probe)
@@ -2109,7 +2112,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RS_VGPR_LI
 
 // the same grid with the streaming workgroups' second form (hg_streamer2.hip.h: the refill's dots as integer matrix products)
 template <int T, int DBG, int MISS>
-__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RL_VGPR_LIMIT))) void k_sweep_limb(ResParams p, const ResParams* pg)
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RL_VGPR_LIMIT / 2))) void k_sweep_limb(ResParams p, const ResParams* pg)
 {
     if (!rs_rendezvous(p, hg_smem)) return;
     if (p.M == 0xffffffffu) {
@@ -2117,6 +2120,20 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RL_VGPR_LI
         return;
     }
     if (blockIdx.x < p.W) res_streamer_limb<T, DBG, MISS>(p, hg_smem);
+    else if (p.walker == 2) res_walker2<DBG, MISS>(*pg);
+    else res_walker<DBG, MISS>(*pg, hg_smem);
+}
+
+// (four tiles per workgroup: 32 bytes of a column per lane and group -- more named registers, hence a register cap of its own)
+template <int DBG, int MISS>
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_num_vgpr(RL_VGPR_LIMIT4 / 2))) void k_sweep_limb4(ResParams p, const ResParams* pg)
+{
+    if (!rs_rendezvous(p, hg_smem)) return;
+    if (p.M == 0xffffffffu) {
+        if (p.nranks > 1) rs_probe_peers(p);
+        return;
+    }
+    if (blockIdx.x < p.W) res_streamer_limb<4, DBG, MISS>(p, hg_smem);
     else if (p.walker == 2) res_walker2<DBG, MISS>(*pg);
     else res_walker<DBG, MISS>(*pg, hg_smem);
 }

@@ -29,8 +29,11 @@
 
 namespace hg {
 
-constexpr int RL_NG = 8;           // register sets: groups of sixteen columns a wave has in registers or on their way (128 positions)
-constexpr int RL_VGPR_LIMIT = 200; // v200 .. v215: the sets' (mave | mstd | flags), v216 .. v223: the ids of the sets' next groups, v224 .. v255: the sets
+constexpr int RL_NG = 8;           // register sets: groups of sixteen columns a wave has in registers or on their way (128 positions; T = 4: four sets, 64 positions)
+constexpr int RL_VGPR_LIMIT = 200; // v200 .. v215: the sets' (mave | mstd), v216 .. v223: the ids of the sets' next groups, v224 .. v255: the sets
+constexpr int RL_VGPR_LIMIT4 = 208; // T = 4 (32 bytes of a column per lane, FOUR sets: 64 positions): v208 .. v215, v216 .. v219, v224 .. v255
+// (the attribute amdgpu_num_vgpr counts the unified VGPR + AGPR file on this target: HALF the limit is what caps the compiler's own registers)
+constexpr int RL_TMAX = 4;         // tiles per workgroup in this form: eps is 2 T doubles per lane, the window's codes B x 256 T bytes (B = 128 at T = 4)
 constexpr int RL_EX = 44;          // eps digits: units of 2^-44
 constexpr uint32_t RL_BLK = 144;   // bytes of a block of sixteen individuals in the digit image: 7 x 16 in use, padded so that the lanes' writes spread over the banks
 typedef int rl_v4i __attribute__((ext_vector_type(4)));
@@ -42,29 +45,54 @@ __host__ __device__ constexpr size_t rl_acc_off(uint32_t B) { return 512 + (size
 __host__ __device__ constexpr size_t rl_acc2_off(uint32_t B) { return 512 + (size_t)B * 24; }
 __host__ __device__ constexpr size_t rl_zero_off(uint32_t B) { return 512 + (size_t)B * 32; }
 __host__ __device__ constexpr size_t rl_digit_off(uint32_t B) { return rl_zero_off(B) + 64; }
-__host__ __device__ constexpr size_t rl_ring_off(uint32_t B, int T) { return rl_digit_off(B) + (size_t)RS_WAVES * 8 * T * RL_BLK; }
+__host__ __device__ constexpr int rl_image_blocks(int T) { return 8 * T < 16 ? 8 * T : 16; } // blocks of sixteen individuals in a wave's digit image (T = 4: made in two halves)
+__host__ __device__ constexpr size_t rl_ring_off(uint32_t B, int T) { return rl_digit_off(B) + (size_t)RS_WAVES * rl_image_blocks(T) * RL_BLK; }
 __host__ __device__ constexpr size_t rl_streamer_lds(uint32_t B, int T) { return rl_ring_off(B, T) + (size_t)B * 256 * T; }
-static_assert(rl_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024, "the largest window at the most tiles per workgroup fits the 160 KB of LDS of a compute unit");
+static_assert(rl_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024 && rl_streamer_lds(RS_BMAX / 2, RL_TMAX) <= 160 * 1024,
+              "the largest window at the most tiles per workgroup fits the 160 KB of LDS of a compute unit");
 
 // ---- the sets: named registers, loads the compiler does not see as loads (hg_resident.hip.h explains why) ----
+// T = 1, 2: set r = v[224 + 4 r .. 227 + 4 r] (T = 1: the first two), the column's (mave | mstd) v[200 + 2 r, 201 + 2 r], the next id v(216 + r)
 #define RL_SET_LIST(X) X(0, 224, 225, 226, 227, 200, 201, 216) X(1, 228, 229, 230, 231, 202, 203, 217) X(2, 232, 233, 234, 235, 204, 205, 218) X(3, 236, 237, 238, 239, 206, 207, 219) \
     X(4, 240, 241, 242, 243, 208, 209, 220) X(5, 244, 245, 246, 247, 210, 211, 221) X(6, 248, 249, 250, 251, 212, 213, 222) X(7, 252, 253, 254, 255, 214, 215, 223)
+// T = 4: four sets, set r = v[224 + 8 r .. 231 + 8 r], (mave | mstd) v[208 + 2 r, 209 + 2 r], the next id v(216 + r)
+#define RL4_SET_LIST(X) X(0, 224, 225, 226, 227, 228, 229, 230, 231, 208, 209, 216) X(1, 232, 233, 234, 235, 236, 237, 238, 239, 210, 211, 217) \
+    X(2, 240, 241, 242, 243, 244, 245, 246, 247, 212, 213, 218) X(3, 248, 249, 250, 251, 252, 253, 254, 255, 214, 215, 219)
 // set R takes 8 T bytes of a column per lane (T = 1: the first two registers of the set)
 template <int T, int R>
 __device__ __forceinline__ void rl_set_load(const uint8_t* addr)
 {
+    if constexpr (T == 4) {
+#define RL_X(r, a, b, c, d, e, f, g, h, m0, m1, id)                                                                                     \
+    if constexpr (R == r)                                                                                                              \
+        asm volatile("global_load_dwordx4 v[" #a ":" #d "], %0, off\n\tglobal_load_dwordx4 v[" #e ":" #h "], %0, off offset:16" ::"v"(addr) \
+                     : "memory", "v" #a, "v" #b, "v" #c, "v" #d, "v" #e, "v" #f, "v" #g, "v" #h);
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, a, b, c, d, m0, m1, id)                                                                                             \
     if constexpr (R == r) {                                                                                                        \
         if constexpr (T == 1) asm volatile("global_load_dwordx2 v[" #a ":" #b "], %0, off" ::"v"(addr) : "memory", "v" #a, "v" #b); \
         else asm volatile("global_load_dwordx4 v[" #a ":" #d "], %0, off" ::"v"(addr) : "memory", "v" #a, "v" #b, "v" #c, "v" #d);  \
     }
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
 }
 // the set's dwords, masked (keep: the lane's valid individuals)
 template <int T, int R>
 __device__ __forceinline__ void rl_set_read(uint32_t (&w)[2 * T], const uint32_t (&keep)[2 * T])
 {
+    if constexpr (T == 4) {
+#define RL_X(r, a, b, c, d, e, f, g, h, m0, m1, id)                                                                                                  \
+    if constexpr (R == r)                                                                                                                           \
+        asm volatile("v_and_b32 %0, v" #a ", %8\n\tv_and_b32 %1, v" #b ", %9\n\tv_and_b32 %2, v" #c ", %10\n\tv_and_b32 %3, v" #d ", %11\n\t"          \
+                     "v_and_b32 %4, v" #e ", %12\n\tv_and_b32 %5, v" #f ", %13\n\tv_and_b32 %6, v" #g ", %14\n\tv_and_b32 %7, v" #h ", %15"              \
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2 * T - 6]), "=&v"(w[2 * T - 5]), "=&v"(w[2 * T - 4]), "=&v"(w[2 * T - 3]), "=&v"(w[2 * T - 2]), "=&v"(w[2 * T - 1]) \
+                     : "v"(keep[0]), "v"(keep[1]), "v"(keep[2 * T - 6]), "v"(keep[2 * T - 5]), "v"(keep[2 * T - 4]), "v"(keep[2 * T - 3]), "v"(keep[2 * T - 2]), "v"(keep[2 * T - 1]));
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, a, b, c, d, m0, m1, id)                                                                                                          \
     if constexpr (R == r) {                                                                                                                     \
         if constexpr (T == 1) asm volatile("v_and_b32 %0, v" #a ", %2\n\tv_and_b32 %1, v" #b ", %3" : "=&v"(w[0]), "=&v"(w[1]) : "v"(keep[0]), "v"(keep[1])); \
@@ -72,44 +100,73 @@ __device__ __forceinline__ void rl_set_read(uint32_t (&w)[2 * T], const uint32_t
                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2 * T - 2]), "=&v"(w[2 * T - 1])                                                   \
                           : "v"(keep[0]), "v"(keep[1]), "v"(keep[2 * T - 2]), "v"(keep[2 * T - 1]));                                              \
     }
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
 }
 // the id of the column this lane takes when set R is loaded next, and (wave 0) the 8 bytes that travel with the set's column of this
 // lane: k-group 0 its mave, k-group 1 its mstd
-template <int R>
+template <int T, int R>
 __device__ __forceinline__ void rl_id_load(const int32_t* id)
 {
+    if constexpr (T == 4) {
+#define RL_X(r, a, b, c, d, e, f, g, h, m0, m1, idr) \
+    if constexpr (R == r) asm volatile("global_load_dword v" #idr ", %0, off" ::"v"(id) : "memory", "v" #idr);
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, a, b, c, d, m0, m1, idr) \
     if constexpr (R == r) asm volatile("global_load_dword v" #idr ", %0, off" ::"v"(id) : "memory", "v" #idr);
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
 }
-template <int R>
+template <int T, int R>
 __device__ __forceinline__ int32_t rl_id_read()
 {
     int32_t v = 0;
+    if constexpr (T == 4) {
+#define RL_X(r, a, b, c, d, e, f, g, h, m0, m1, idr) \
+    if constexpr (R == r) asm volatile("v_mov_b32 %0, v" #idr : "=v"(v));
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, a, b, c, d, m0, m1, idr) \
     if constexpr (R == r) asm volatile("v_mov_b32 %0, v" #idr : "=v"(v));
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
     return v;
 }
-template <int R>
+template <int T, int R>
 __device__ __forceinline__ void rl_meta_load(const double* a)
 {
+    if constexpr (T == 4) {
+#define RL_X(r, sa, sb, sc, sd, se, sf, sg, sh, m0, m1, idr) \
+    if constexpr (R == r) asm volatile("global_load_dwordx2 v[" #m0 ":" #m1 "], %0, off" ::"v"(a) : "memory", "v" #m0, "v" #m1);
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, sa, sb, sc, sd, m0, m1, idr) \
     if constexpr (R == r) asm volatile("global_load_dwordx2 v[" #m0 ":" #m1 "], %0, off" ::"v"(a) : "memory", "v" #m0, "v" #m1);
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
 }
-template <int R>
+template <int T, int R>
 __device__ __forceinline__ void rl_meta_read(int& lo, int& hi)
 {
+    if constexpr (T == 4) {
+#define RL_X(r, sa, sb, sc, sd, se, sf, sg, sh, m0, m1, idr) \
+    if constexpr (R == r) asm volatile("v_mov_b32 %0, v" #m0 "\n\tv_mov_b32 %1, v" #m1 : "=&v"(lo), "=&v"(hi));
+        RL4_SET_LIST(RL_X)
+#undef RL_X
+    } else {
 #define RL_X(r, sa, sb, sc, sd, m0, m1, idr) \
     if constexpr (R == r) asm volatile("v_mov_b32 %0, v" #m0 "\n\tv_mov_b32 %1, v" #m1 : "=&v"(lo), "=&v"(hi));
-    RL_SET_LIST(RL_X)
+        RL_SET_LIST(RL_X)
 #undef RL_X
+    }
 }
 
 // sixteen 2-bit codes -> four dwords of bytes: dword r, byte i = the code of individual 4 i + r of the sixteen
@@ -137,6 +194,7 @@ template <int T, int DBG, int MISS>
 __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned char* smem)
 {
     constexpr int ND = 2 * T;      // dwords of a column per lane and group of sixteen columns = k-steps per group = individuals per lane
+    constexpr int NG = T == 4 ? 4 : RL_NG; // register sets
     constexpr int LPB = 8 / T;     // lanes that own a block of sixteen individuals
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +207,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
     unsigned long long* const acc1 = reinterpret_cast<unsigned long long*>(smem + rl_acc_off(B));  // [position - Sx] this round's refill: the column's dot, integer units of 2^-44
     unsigned long long* const acc2 = reinterpret_cast<unsigned long long*>(smem + rl_acc2_off(B)); // build MISS: the same for R
     unsigned char* const zero16 = smem + rl_zero_off(B);
-    unsigned char* const dimg = smem + rl_digit_off(B) + (size_t)wave * (8 * T * RL_BLK); // this wave's digit image: [block of sixteen individuals][digit][16 bytes in A's order]
+    unsigned char* const dimg = smem + rl_digit_off(B) + (size_t)wave * (rl_image_blocks(T) * RL_BLK); // this wave's digit image: [block of sixteen individuals][digit][16 bytes in A's order] (T = 4: half of the blocks at a time)
     uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + rl_ring_off(B, T));       // [B][64 * T] codes of the window columns (x form)
     if (tid < 16) reinterpret_cast<uint32_t*>(zero16)[tid] = 0u;
     for (uint32_t i = (uint32_t)tid; i < 2u * B; i += RS_BLOCK) acc1[i] = 0ull; // (acc1 and acc2 are adjacent)
@@ -179,16 +237,18 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
         const uint32_t nv = (!vcol || i0 >= p.n_local) ? 0u : (p.n_local - i0 >= 16u ? 16u : p.n_local - i0);
         keep[d] = nv >= 16u ? 0xffffffffu : ((1u << (2u * nv)) - 1u);
     }
-    // eps: lane l owns 2 T individuals of block bw = l / LPB of the wave's 8 T: b = r4 + 4 (hq 2 T + s), s < 2 T, with r4 = (l % LPB) & 3, hq = (l % LPB) >> 2
-    // (the four -- two -- bytes of ONE dword of A's order: dword r4, bytes hq 2 T + s)
-    const uint32_t bw = (uint32_t)lane / (uint32_t)LPB, ml = (uint32_t)lane % (uint32_t)LPB, r4 = ml & 3u, hq = ml >> 2;
+    // eps: lane l owns 2 T individuals of block bw = l / LPB of the wave's 8 T -- whole dwords of A's order (dword r = the individuals r, 4 + r,
+    // 8 + r, 12 + r of the block) or, at T = 1, half of one: T = 1: dword r4 = m & 3, bytes 2 hq, 2 hq + 1 (m = l % 8, hq = m >> 2); T = 2: dword m
+    // (m = l % 4); T = 4: dwords 2 m, 2 m + 1 (m = l % 2)
+    const uint32_t bw = (uint32_t)lane / (uint32_t)LPB, ml = (uint32_t)lane % (uint32_t)LPB;
+    const uint32_t r4 = T == 4 ? 2u * ml : (ml & 3u), hq = T == 1 ? ml >> 2 : 0u;
     const uint32_t De = wg * 64u * T + (uint32_t)wave * 8u * T + bw;   // the block's dword in the shard
     double e[ND];
     uint32_t eb[ND]; // the individuals' index within their block
     bool ev[ND];     // ... is an individual of the shard (padding stays zero)
 #pragma unroll
     for (int s = 0; s < ND; ++s) {
-        eb[s] = r4 + 4u * (hq * (uint32_t)ND + (uint32_t)s);
+        eb[s] = T == 4 ? (r4 + ((uint32_t)s >> 2)) + 4u * ((uint32_t)s & 3u) : r4 + 4u * (hq * (uint32_t)ND + (uint32_t)s);
         const uint32_t i = De * 16u + eb[s];
         ev[s] = De < ndw && i < p.n_local;
         e[s] = ev[s] ? p.eps[eps_pos(i)] : 0.0;
@@ -204,37 +264,59 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
             big = big || !(fabs(e[s]) < 64.0);
         }
         if (big) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
-        unsigned char* const blk = dimg + bw * RL_BLK + r4 * 4u + hq * (uint32_t)ND;
-        if constexpr (T == 2) {
-            // 4 x 4 byte transposes: digit j of the lane's four individuals in one dword (byte s = individual s)
-            auto tr4 = [&](const uint32_t (&x)[ND], int jbase, int nj) {
-                const uint32_t t0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u), t1 = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);
-                const uint32_t u0 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u), u1 = __builtin_amdgcn_perm(x[3], x[2], 0x07030602u);
-                *reinterpret_cast<uint32_t*>(blk + (jbase + 0) * 16) = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
-                *reinterpret_cast<uint32_t*>(blk + (jbase + 1) * 16) = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
-                *reinterpret_cast<uint32_t*>(blk + (jbase + 2) * 16) = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
-                if (nj > 3) *reinterpret_cast<uint32_t*>(blk + (jbase + 3) * 16) = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
-            };
-            tr4(lo, 0, 4);
-            tr4(hi, 4, 3);
-        } else {
-            // two individuals: digit j = bytes (x0.j, x1.j)
-            auto tr2 = [&](const uint32_t (&x)[ND], int jbase, int nj) {
-                const uint32_t t0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u), t1 = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);
-                *reinterpret_cast<uint16_t*>(blk + (jbase + 0) * 16) = (uint16_t)t0;
-                *reinterpret_cast<uint16_t*>(blk + (jbase + 1) * 16) = (uint16_t)(t0 >> 16);
-                *reinterpret_cast<uint16_t*>(blk + (jbase + 2) * 16) = (uint16_t)t1;
-                if (nj > 3) *reinterpret_cast<uint16_t*>(blk + (jbase + 3) * 16) = (uint16_t)(t1 >> 16);
-            };
-            tr2(lo, 0, 4);
-            tr2(hi, 4, 3);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the wave's own writes: in order with its reads -- made explicit for the compiler)
-        __builtin_amdgcn_wave_barrier();
+        // 4 x 4 byte transposes: digit j of four individuals in one dword (byte s = individual s of the four)
+        auto tr4 = [&](unsigned char* blk, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, int jbase, int nj) {
+            const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), u1 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+            *reinterpret_cast<uint32_t*>(blk + (jbase + 0) * 16) = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(blk + (jbase + 1) * 16) = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+            *reinterpret_cast<uint32_t*>(blk + (jbase + 2) * 16) = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+            if (nj > 3) *reinterpret_cast<uint32_t*>(blk + (jbase + 3) * 16) = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+        };
+        auto operands = [&](uint32_t first_block) { // the lane's operand registers of the blocks that are in the image now
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const unsigned char* src = cl < 7u ? dimg + (gl * (uint32_t)ND + (uint32_t)d) * RL_BLK + cl * 16u : zero16;
-            bop[d] = *reinterpret_cast<const rl_v4i*>(src);
+            for (int d = 0; d < ND; ++d) {
+                const unsigned char* src = cl < 7u ? dimg + (gl * (uint32_t)ND + (uint32_t)d - first_block) * RL_BLK + cl * 16u : zero16;
+                bop[d] = *reinterpret_cast<const rl_v4i*>(src);
+            }
+        };
+        if constexpr (T == 4) {
+            // the image holds sixteen blocks: the lanes 0 .. 31 own the blocks 0 .. 15 (read by the k-groups 0 and 1), the lanes 32 .. 63 the rest
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (((uint32_t)lane >> 5) == (uint32_t)h) {
+                    unsigned char* const blk = dimg + (bw & 15u) * RL_BLK + r4 * 4u;
+                    tr4(blk, lo[0], lo[1], lo[2], lo[3], 0, 4);
+                    tr4(blk, hi[0], hi[1], hi[2], hi[3], 4, 3);
+                    tr4(blk + 4, lo[ND - 4], lo[ND - 3], lo[ND - 2], lo[ND - 1], 0, 4);
+                    tr4(blk + 4, hi[ND - 4], hi[ND - 3], hi[ND - 2], hi[ND - 1], 4, 3);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if ((gl >> 1) == (uint32_t)h) operands(16u * (uint32_t)h);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (read before the other half overwrites the image)
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            unsigned char* const blk = dimg + bw * RL_BLK + r4 * 4u + hq * (uint32_t)ND;
+            if constexpr (T == 2) {
+                tr4(blk, lo[0], lo[1], lo[ND - 2], lo[ND - 1], 0, 4);
+                tr4(blk, hi[0], hi[1], hi[ND - 2], hi[ND - 1], 4, 3);
+            } else {
+                // two individuals: digit j = bytes (x0.j, x1.j)
+                auto tr2 = [&](const uint32_t (&x)[ND], int jbase, int nj) {
+                    const uint32_t t0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u), t1 = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);
+                    *reinterpret_cast<uint16_t*>(blk + (jbase + 0) * 16) = (uint16_t)t0;
+                    *reinterpret_cast<uint16_t*>(blk + (jbase + 1) * 16) = (uint16_t)(t0 >> 16);
+                    *reinterpret_cast<uint16_t*>(blk + (jbase + 2) * 16) = (uint16_t)t1;
+                    if (nj > 3) *reinterpret_cast<uint16_t*>(blk + (jbase + 3) * 16) = (uint16_t)(t1 >> 16);
+                };
+                tr2(lo, 0, 4);
+                tr2(hi, 4, 3);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the wave's own writes: in order with its reads -- made explicit for the compiler)
+            __builtin_amdgcn_wave_barrier();
+            operands(0u);
         }
     };
     __syncthreads(); // (the zeros, the accumulators)
@@ -246,8 +328,8 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
     bool count_due = false; // (last wave) this round's adds are out, the batch counter's is not
     bool last = M == 0;
     double dbeta = 0.0;
-    // Set r holds the group H_r of sixteen positions [16 H_r, 16 H_r + 16) -- the first group = r (mod RL_NG) that is not admitted to the
-    // window in full; it is reloaded (group H_r + RL_NG) right after the round that admits its last column.
+    // Set r holds the group H_r of sixteen positions [16 H_r, 16 H_r + 16) -- the first group = r (mod NG) that is not admitted to the
+    // window in full; it is reloaded (group H_r + NG) right after the round that admits its last column.
     auto cols_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // (the lane's array of the two, as a VALUE made once: selected inside the loop the compiler reads the pointer from the kernel's arguments
     // at a per-lane address -- a load in front of the set's loads, and its wait is for everything in flight)
@@ -261,18 +343,18 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
         constexpr int r = decltype(rtag)::value;
         const uint32_t pn = 16u * G + cl;
         rl_set_load<T, r>(p.bed + ((size_t)((uint32_t)(pn < M ? id : 0) * (uint32_t)(p.stride >> 10)) << 10) + coff);
-        const uint32_t pi = 16u * (G + (uint32_t)RL_NG) + cl; // the id of the set's next column
-        rl_id_load<r>(p.order + (pi < M ? pi : 0u));
-        if (wave == 0 && gl < 2u) rl_meta_load<r>(mbase + (pn < M ? pn : 0u)); // what travels with the column: k-group 0 its mave, k-group 1 its mstd
+        const uint32_t pi = 16u * (G + (uint32_t)NG) + cl; // the id of the set's next column
+        rl_id_load<T, r>(p.order + (pi < M ? pi : 0u));
+        if (wave == 0 && gl < 2u) rl_meta_load<T, r>(mbase + (pn < M ? pn : 0u)); // what travels with the column: k-group 0 its mave, k-group 1 its mstd
     };
     {
-        int32_t id0[RL_NG];
+        int32_t id0[NG];
 #pragma unroll
-        for (int r = 0; r < RL_NG; ++r) {
+        for (int r = 0; r < NG; ++r) {
             const uint32_t pn = 16u * (uint32_t)r + cl;
             id0[r] = p.order[pn < M ? pn : 0u];
         }
-        [&]<int... R>(std::integer_sequence<int, R...>) { (load_set(std::integral_constant<int, R>{}, (uint32_t)R, id0[R]), ...); }(std::make_integer_sequence<int, RL_NG>{});
+        [&]<int... R>(std::integer_sequence<int, R...>) { (load_set(std::integral_constant<int, R>{}, (uint32_t)R, id0[R]), ...); }(std::make_integer_sequence<int, NG>{});
     }
 
     // wait for the walker's message number seq (one lane polls; everybody else sleeps at the barrier); behind an announcement: for the
@@ -366,11 +448,11 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
         // G0 .. G1 of sixteen, every wave its slice of every column ----
         if (nnew) {
             const uint32_t G0 = Sx >> 4, G1 = (Sn - 1u) >> 4;
-            for (uint32_t gb = G0; gb <= G1; gb += (uint32_t)RL_NG) { // (more than RL_NG groups: the first fill, a long advance)
+            for (uint32_t gb = G0; gb <= G1; gb += (uint32_t)NG) { // (more than NG groups: the first fill, a long advance)
                 if (gb != G0) cols_landed();
                 auto one = [&](auto rtag) __attribute__((always_inline)) {
                     constexpr int r = decltype(rtag)::value;
-                    const uint32_t G = gb + (((uint32_t)r - gb) & (uint32_t)(RL_NG - 1));
+                    const uint32_t G = gb + (((uint32_t)r - gb) & (uint32_t)(NG - 1));
                     if (G <= G1) { // wave-uniform
                         uint32_t w[ND];
                         rl_set_read<T, r>(w, keep);
@@ -378,7 +460,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                         const bool mine = pc >= Sx && pc < Sn;
                         bool anym = false;
                         int mlo = 0, mhi = 0;
-                        if (wave == 0) rl_meta_read<r>(mlo, mhi); // (wave 0 fills the slots' (mave, mstd))
+                        if (wave == 0) rl_meta_read<T, r>(mlo, mhi); // (wave 0 fills the slots' (mave, mstd))
                         if constexpr (MISS) {
                             // a column with missing calls is known by its codes: 11 anywhere in the group's dwords of this wave (no flag needed)
                             uint32_t any3 = 0u;
@@ -409,7 +491,10 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                         // the window keeps the x form: what the update's table and the Gram terms of every later event need, made once
                         if (mine) {
                             uint32_t* rp = ring + (pc & bmask) * 64u * T + Dc;
-                            if constexpr (T == 2) *reinterpret_cast<u4_t*>(rp) = rs_u4(xf[0], xf[1], xf[ND - 2], xf[ND - 1]);
+                            if constexpr (T == 4) {
+                                *reinterpret_cast<u4_t*>(rp) = rs_u4(xf[0], xf[1], xf[ND - 6], xf[ND - 5]);
+                                *reinterpret_cast<u4_t*>(rp + 4) = rs_u4(xf[ND - 4], xf[ND - 3], xf[ND - 2], xf[ND - 1]);
+                            } else if constexpr (T == 2) *reinterpret_cast<u4_t*>(rp) = rs_u4(xf[0], xf[1], xf[ND - 2], xf[ND - 1]);
                             else *reinterpret_cast<uint2*>(rp) = make_uint2(xf[0], xf[1]);
                             if (wave == 0 && gl < 2u) reinterpret_cast<double*>(meta + (pc & bmask))[gl] = __hiloint2double(mhi, mlo);
                         }
@@ -433,10 +518,10 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                             }
                         }
                         // the set's group is admitted in full: its next group leaves HBM now (waited for by hand, at the top of the next round)
-                        if (16u * G + 16u <= Sn && !last) load_set(rtag, G + (uint32_t)RL_NG, rl_id_read<r>());
+                        if (16u * G + 16u <= Sn && !last) load_set(rtag, G + (uint32_t)NG, rl_id_read<T, r>());
                     }
                 };
-                [&]<int... R>(std::integer_sequence<int, R...>) { (one(std::integral_constant<int, R>{}), ...); }(std::make_integer_sequence<int, RL_NG>{});
+                [&]<int... R>(std::integer_sequence<int, R...>) { (one(std::integral_constant<int, R>{}), ...); }(std::make_integer_sequence<int, NG>{});
             }
         }
         lap(3);

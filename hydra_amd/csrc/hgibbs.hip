@@ -154,7 +154,7 @@ struct hgibbs_ctx {
     uint32_t window = 0;      // option window: columns kept in LDS per streaming workgroup (0 auto; power of two <= 256)
     uint32_t res_cus = 0;     // option res_cus: compute units the resident engine may use (0 = all)
     int res_walker = 0;       // option walker: 0 auto (the second where it applies), 1 the first walker, 2 the second (hg_walker2.hip.h; refused where it does not apply)
-    bool res_attr_set[16] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
+    bool res_attr_set[20] = {}; // the resident kernels whose LDS opt-in has been made on THIS handle's device
     bool res_dead = false;     // a resident kernel did not come back even after the abort word: the stream (and the handle) cannot be used any more
     uint32_t res_probed_w = 0;     // several ranks: the grid size the probe launch has found resident together with the peers' (0: not yet)
     unsigned long long res_probe_id = 0;
@@ -1337,6 +1337,7 @@ struct ResPlan {
     uint32_t B = 0;   // window
 };
 
+static int resident_refill(const hgibbs_ctx* h);
 // nullptr when the resident engine can run this handle's sweeps, else the reason why not
 static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
 {
@@ -1349,7 +1350,14 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     if (cus < 2) return "fewer than two compute units";
     const uint32_t ntile = h->n_pad / TILE;
     uint32_t T = (ntile + (cus - 1) - 1) / (cus - 1);
-    if (T > (uint32_t)RS_TMAX) return "more individuals than the compute units hold in registers (2048 each)";
+    if (T > (uint32_t)RS_TMAX) {
+        // four tiles per workgroup: the second form of the streaming workgroups only (eps is 2 T doubles per lane there; the window
+        // shrinks to 128 columns to make room for their codes), one rank, no predicted pivots, a residual inside the digits' range
+        const bool four = T <= (uint32_t)RL_TMAX && h->nranks <= 1 && resident_refill(h) == 2;
+        if (!four) return T <= (uint32_t)RL_TMAX ? "more than 2048 individuals per compute unit need the second form of the streaming workgroups on one rank (option refill, |eps| < 32)"
+                                                  : "more individuals than the compute units hold (4096 each)";
+        T = (uint32_t)RL_TMAX;
+    }
     if ((h->stride & 1023u) || (uint64_t)h->M * (h->stride >> 10) >= (1ull << 32)) return "a shard's BED columns are addressed in 32 bits of KiB";
     pl->T = (int)T;
     pl->W = (ntile + T - 1) / T;
@@ -1374,7 +1382,7 @@ static int resident_refill(const hgibbs_ctx* h)
 }
 static size_t resident_streamer_lds(const hgibbs_ctx* h, const ResPlan& pl)
 {
-    if (resident_refill(h) == 2) return rl_streamer_lds(pl.B, pl.T);
+    if (resident_refill(h) == 2 || pl.T == RL_TMAX) return rl_streamer_lds(pl.B, pl.T);
     return h->any_missing ? rs_streamer_lds_miss(pl.B, pl.T) : rs_streamer_lds(pl.B, pl.T);
 }
 
@@ -1384,9 +1392,10 @@ static int resident_kernel(hgibbs_ctx* h, const ResPlan& pl, void (**out)(ResPar
     void (*kern)(ResParams, const ResParams*) = nullptr;
     const bool dbg = h->debug_timing;
     const bool miss = h->any_missing; // the build that keeps s2 per column and the four-term Gram sums
-    const bool limb = resident_refill(h) == 2;
+    const bool limb = resident_refill(h) == 2 || pl.T == RL_TMAX;
     if (limb) {
         switch (pl.T) {
+        case 4: kern = miss ? (dbg ? k_sweep_limb4<1, 1> : k_sweep_limb4<0, 1>) : (dbg ? k_sweep_limb4<1, 0> : k_sweep_limb4<0, 0>); break;
         case 1: kern = miss ? (dbg ? k_sweep_limb<1, 1, 1> : k_sweep_limb<1, 0, 1>) : (dbg ? k_sweep_limb<1, 1, 0> : k_sweep_limb<1, 0, 0>); break;
         default: kern = miss ? (dbg ? k_sweep_limb<2, 1, 1> : k_sweep_limb<2, 0, 1>) : (dbg ? k_sweep_limb<2, 1, 0> : k_sweep_limb<2, 0, 0>); break;
         }
@@ -1396,7 +1405,7 @@ static int resident_kernel(hgibbs_ctx* h, const ResPlan& pl, void (**out)(ResPar
         default: kern = miss ? (dbg ? k_sweep_resident<2, 1, 1> : k_sweep_resident<2, 0, 1>) : (dbg ? k_sweep_resident<2, 1, 0> : k_sweep_resident<2, 0, 0>); break;
         }
     }
-    const int ai = (limb ? 8 : 0) + (pl.T == 1 ? 0 : 1) * 4 + (dbg ? 2 : 0) + (miss ? 1 : 0);
+    const int ai = (pl.T == RL_TMAX ? 16 : (limb ? 8 : 0) + (pl.T == 1 ? 0 : 1) * 4) + (dbg ? 2 : 0) + (miss ? 1 : 0);
     if (!h->res_attr_set[ai]) { // (per handle: the attribute belongs to the function ON A DEVICE)
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->res_attr_set[ai] = true;
@@ -1507,7 +1516,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.timeout = (unsigned long long)(h->res_timeout_s * 1e8);
     p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8); // the grid's workgroups start within microseconds of each other -- or not at all
     p.dbg = h->debug_timing ? 1 : 0;
-    p.pivots = (h->nranks > 1 || h->any_missing || resident_refill(h) == 2) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
+    p.pivots = (h->nranks > 1 || h->any_missing || resident_refill(h) == 2 || pl.T == RL_TMAX) ? 0 : h->res_pivots; // (the pivot terms have no cross-rank exchange and no four-term form)
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
@@ -1638,7 +1647,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     s.tiles_per_workgroup_min = s.tiles_per_workgroup_max = (uint32_t)pl.T;
     s.engine = 2;
     s.walker = (uint32_t)p.walker;
-    s.refill = (uint32_t)resident_refill(h);
+    s.refill = (uint32_t)(pl.T == RL_TMAX ? 2 : resident_refill(h));
     s.rounds = st.rounds;
     s.events = st.events;
     s.advances = st.advances;

@@ -95,4 +95,4 @@ def test_inline_assembly_lds_reads_are_not_touched_before_their_wait(tmp_path):
     # but the walkers (tools/asm_check_loads.py; hg_resident.hip.h, hg_streamer2.hip.h)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_check_loads.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "violations: 0" in r.stdout and "kernels checked: 16" in r.stdout  # two forms x T = 1, 2 x stage clocks on/off x missing-call build on/off
+    assert "violations: 0" in r.stdout and "kernels checked: 20" in r.stdout  # two forms x T = 1, 2 (+ T = 4 of the second) x stage clocks on/off x missing-call build on/off

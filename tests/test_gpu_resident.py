@@ -87,6 +87,14 @@ def test_tiles_per_workgroup(oracle, cus, T, refill):
     run_vs_oracle(oracle, 400, 8000, opts={"res_cus": cus, "refill": refill}, expect_T=T, expect_refill=refill)
 
 
+@pytest.mark.parametrize("N,cus,miss", [(8000, 3, 0.0), (8000, 3, 0.03), (20011, 6, 0.0), (14001, 5, 0.02)])
+def test_four_tiles_per_workgroup(oracle, N, cus, miss):
+    """More than 2048 individuals per compute unit: the second form of the streaming workgroups holds four tiles (32 bytes of a column per
+    lane and group of sixteen, the digit image made in two halves, a 128-column window) -- shards of up to 255 x 4096 individuals stay on
+    the resident engine.  8 tiles on 2 streaming workgroups, 20 on 5, 14 on 4 (the last one ragged); clean and with missing calls."""
+    ch, ref, dev = run_vs_oracle(oracle, 400, N, iters=3, opts={"res_cus": cus}, expect_T=4, expect_refill=2, missing_rate=miss)
+
+
 def test_many_workgroups_multishard(oracle):
     # 20 wave tiles -> 20 streaming workgroups over 8 Gram shards and 4 raw-dot shards
     run_vs_oracle(oracle, 400, 20011, iters=3)

@@ -12,7 +12,7 @@ usage: asm_check_loads.py file.s   (exit 1 on a violation)"""
 import re
 import sys
 
-LIMITS = {"k_sweep_resident": 216, "k_sweep_limb": 200}  # hg_resident.hip.h: RS_VGPR_LIMIT; hg_streamer2.hip.h: RL_VGPR_LIMIT (the same discipline, more named registers)
+LIMITS = {"k_sweep_resident": 216, "k_sweep_limb": 200, "k_sweep_limb4": 208}  # hg_resident.hip.h: RS_VGPR_LIMIT; hg_streamer2.hip.h: RL_VGPR_LIMIT (the same discipline, more named registers)
 text = open(sys.argv[1]).read().splitlines()
 
 
@@ -28,7 +28,7 @@ funcs = {m.group(1) for t in text for m in [re.match(r"^\s*\.type\s+(\S+),@funct
 bad = checked = 0
 i, n = 0, len(text)
 while i < n:
-    m = re.match(r"^(\S*(k_sweep_resident|k_sweep_limb)\S*):\s", text[i])
+    m = re.match(r"^(\S*?(k_sweep_resident|k_sweep_limb4|k_sweep_limb)I\S*):\s", text[i])
     if m and not text[i].startswith("."):
         LIMIT = LIMITS[m.group(2)]
         name, inasm, loads, reads = m.group(1), False, 0, 0
