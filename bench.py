@@ -595,7 +595,8 @@ def main():
         kernel_ms_avg = sweep_ms / max(1, launches)
         achieved = (bytes_alg / max(1, launches)) / (kernel_ms_avg * 1e-3) / 1e9
         refill = int(stats[-1][0].get("refill", 0))
-        kname = ("k_sweep_limb" if refill == 2 else "k_sweep_resident") if resident else "k_sweep_batch"
+        tiles = int(stats[-1][0].get("tiles_per_workgroup_max", 0))
+        kname = (("k_sweep_limb4" if tiles == 4 else "k_sweep_limb") if refill == 2 else "k_sweep_resident") if resident else "k_sweep_batch"
         traffic, traffic_src = committed_profile("traffic", N, M, world, kname, args.missing)
         valu, valu_src = committed_profile("valu", N, M, world, kname, args.missing)
         anatomy = anatomy_all  # measured by every rank together (below the timed region), reported by rank 0

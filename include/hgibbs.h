@@ -147,7 +147,7 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
  *   engine          0 auto (default): the resident engine where it applies, else the batch engine; 1 batch engine (one launch
  *                   per batch of markers up to an event); 2 resident engine (ONE launch per sweep; the call fails where it does
  *                   not apply: several ranks without peer mailboxes or more than eight, a
- *                   shard of more than 2048 individuals per compute unit, G * K > 256).  Setting any option of the batch
+ *                   shard of more than 4096 individuals per compute unit -- 2048 with several ranks or refill = 1 --, G * K > 256).  Setting any option of the batch
  *                   engine below (a batch width, ...) while engine = 0 selects the batch engine.
  *   window          resident engine: columns kept in LDS behind the cursor, a power of two <= 256 (0 auto: 256)
  *   res_cus         resident engine: compute units to use (0 = all; one of them walks the chain, the others stream)

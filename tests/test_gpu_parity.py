@@ -544,14 +544,15 @@ def test_full_size_properties_c2():
         assert close(res[0][3]["sigmaE"], r[3]["sigmaE"])
 
 
-@pytest.mark.parametrize("cfg", ["c3", "c4", "c4-missing"])
+@pytest.mark.parametrize("cfg", ["c3", "c4", "c4-missing", "n1m"])
 def test_full_size_properties_c3_c4(cfg):
     """BASELINE configs 3 (N=200 000, M=500 000, two groups) and 4 (N=500 000, M=1 000 000: 125 GB of packed
     genotypes in HBM) at full size through the same size-independent properties: counts add up, the residual
     identity eps + X beta == y - mu holds after the sweeps (round trip through the update operator), and the three ways through
     the sweep -- the resident engine (the default at these shapes), the batch engine with Gram corrections, and the batch
     engine's plain path (gram = 0, another batch width) -- walk the same chain."""
-    N, M, G = (200000, 500000, 2) if cfg == "c3" else (500000, 1000000, 1)
+    N, M, G = (200000, 500000, 2) if cfg == "c3" else ((1000000, 60000, 1) if cfg == "n1m" else (500000, 1000000, 1))
+    # ("n1m": a shard of a million individuals on one GPU -- four tiles per workgroup, 245 streaming workgroups of the second form)
     missing = 0.01 if cfg == "c4-missing" else 0.0  # (1 % missing calls in every column: the resident MISS build at 245 workgroups against the batch engine's)
     groups = None if G == 1 else (np.arange(M) % 2).astype(np.int32)
     mS = np.array([[0.0, 0.0001, 0.001, 0.01]]) if G == 1 else np.array([[0.0, 0.001, 0.01, 0.1]] * 2)
@@ -580,6 +581,8 @@ def test_full_size_properties_c3_c4(cfg):
         # it by, measured by the library at sweep end, stays far below the 1e-9 the dots are compared at
         assert drift <= 1e-8 * max(1.0, abs(float(eps.sum()))), drift
         assert dev.sweep_stats()["engine"] == (1 if batch else 2)
+        if cfg == "n1m" and not batch:
+            assert dev.sweep_stats()["tiles_per_workgroup_max"] == 4 and dev.sweep_stats()["refill"] == 2
         assert st["cass"].sum() == M and st["m0"].sum() == (comp != 0).sum()
         assert np.all((beta != 0) == (comp != 0)) and np.all((acum >= 0) & (acum <= 1.0 + 1e-12))
         if gram:
