@@ -216,7 +216,7 @@ static_assert(rs_streamer_lds(RS_BMAX, RS_TMAX) <= 160 * 1024 && rs_streamer_lds
 // streaming workgroup
 // ---------------------------------------------------------------------------------------------------------------
 // The refill's columns land in the TOP 32 vector registers, named by hand: v224 .. v255 are outside what the compiler may allocate
-// (the kernel carries amdgpu_num_vgpr(RS_VGPR_LIMIT)), so nothing but the instructions below ever touches them.  The loads are
+// (the kernel carries a register cap of RS_VGPR_LIMIT, see below), so nothing but the instructions below ever touches them.  The loads are
 // instructions the compiler does not see as loads: it would otherwise place its own wait before the first use of a loaded register,
 // and the only wait it can place there is for ALL vector-memory operations in flight (vmcnt counts in order, the loads are issued
 // under wave-uniform conditions it cannot count) -- for loads issued microseconds ago AND for the ones just issued for the next

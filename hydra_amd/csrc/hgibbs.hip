@@ -1527,7 +1527,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
         if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks)", RS_FG, HT_LDS);
         static const int env_walker = std::getenv("HGIBBS_WALKER") ? std::atoi(std::getenv("HGIBBS_WALKER")) : 0; // (test runs: the default walker of handles that do not set the option)
         const int want = h->res_walker ? h->res_walker : env_walker;
-        p.walker = (want != 1 && w2_ok) ? 2 : 1; // (auto: the second walker where it applies) // (auto: the first walker -- the second is not faster yet)
+        p.walker = (want != 1 && w2_ok) ? 2 : 1; // (auto: the second walker where it applies)
     }
     p.pred = h->pred;
     p.tune = h->res_tune;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the device assembly of the resident sweep kernel (hg_resident.hip.h).  The columns that refill the window land in
 vector registers v224 .. v255 (and the lanes' per-set values in v216 .. v220), named by hand in inline assembly and loaded by
-instructions the compiler does not see as loads; the kernel carries amdgpu_num_vgpr(216), so the compiler must never allocate them.  This script verifies exactly that on the emitted
+instructions the compiler does not see as loads; the kernel carries a register cap (amdgpu_num_vgpr of HALF the limit: the attribute counts the unified VGPR + AGPR file), so the compiler must never allocate them.  This script verifies exactly that on the emitted
 code: in every k_sweep_resident kernel, no instruction outside an inline-assembly block names a register >= v216, and inside
 inline assembly only the expected instructions do (global_load_dword[x2], v_and_b32, v_mov_b32, v_readlane_b32).
 Callees are compiled without that cap, so the kernel body may call nothing but the walkers (res_walker, res_walker2: the walker's
