@@ -198,7 +198,12 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
 {
     Walk2Lds sh;
     const Walk2Off off = walk2_offsets(B);
-    W2_LDS unsigned char* const lbase = (W2_LDS unsigned char*)hg_smem;
+    // The address of the dynamic LDS is not a constant inside a function that is not the kernel: the compiler reads it from a table in global
+    // memory -- and, short of registers, reads it AGAIN wherever an array's address is needed (the chain's loop held a dozen such loads, each
+    // a round trip to L2 with a wait for everything in flight in front of an LDS access).  Read once, kept as an opaque scalar.
+    uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(W2_LDS unsigned char*)hg_smem);
+    asm volatile("" : "+s"(lb));
+    W2_LDS unsigned char* const lbase = (W2_LDS unsigned char*)(uintptr_t)lb;
 #define W2_X(type, name, count) sh.name = (W2_LDS type*)(lbase + off.name);
     W2_ARRAYS(W2_X)
 #undef W2_X
@@ -577,6 +582,11 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         }
         if (failed) break;
         lap(1);
+        // the counters the message's flow control will ask for leave LDS now, all at once, and are looked at behind the exact decision: read
+        // one by one where they are needed they were three trips to LDS in front of every message (their cached values go stale every round)
+        const uint32_t fc_rdone = __hip_atomic_load(sh.sw + S_RDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                       fc_wpub = __hip_atomic_load(sh.sw + S_WPUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                       fc_evw = __hip_atomic_load(sh.sw + S_EVW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0 && (DBG || (n_chunks & 255u) == 0u)) w2_gst(progress, ((unsigned long long)n_rounds << 8) | 1u);
         // fired pivots stay on record only while a column streamed before their update is without its dot (entries are in message order).
         // (The chain waves read the list while they take a record; it changes only here, behind their answers.)
@@ -607,7 +617,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         bool found = false, announced = false;
         uint32_t qpos = 0, q_consumed = 0;
         int q_k = 0;
-        double q_bnew = 0.0, q_bold = 0.0;
+        double q_bnew = 0.0, q_bold = 0.0, q_mq = 0.0, q_sq = 0.0, q_gsq = 0.0, q_nmq = 0.0;
         {
             const uint32_t s0 = C & bmask, i0 = s0 >> 6, l0 = s0 & 63u;
             const unsigned long long lowm = (1ull << l0) - 1ull;
@@ -633,6 +643,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 upos = upos >= W2_RING ? upos - W2_RING : upos;
                 // (one round trip for all of the candidate's values)
                 const double bold_v = sh.bold[ms], num = sh.rnum[qc & (W2_RR - 1u)];
+                const double cmq_v = sh.mave[ms], csq_v = sh.mstd[ms], cgsq_v = MISS ? sh.gsum[ms] : 0.0, cnmq_v = MISS ? sh.nmis[ms] : 0.0; // (for the record, if this one is the event)
                 const int ga_v = sh.ga[ms];
                 const uint32_t word_v = sh.mt[upos];
                 const double bold = w2_uni(bold_v);
@@ -708,6 +719,10 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 }
                 if (k != 0 || bold != 0.0) {
                     found = true;
+                    q_mq = w2_uni(cmq_v);
+                    q_sq = w2_uni(csq_v);
+                    q_gsq = w2_uni(cgsq_v);
+                    q_nmq = w2_uni(cnmq_v);
                     qpos = qc;
                     q_k = k;
                     q_bnew = bnew;
@@ -751,9 +766,16 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             pivot = qpos + 1u >= Sx || pi - w2_uni(sh.bl_pi[w2_uni(sh.batch[(qpos + 1u) & bmask]) % W2_NB]) < (uint32_t)RS_PMAX;
         // flow control: never more than RS_MSG - 3 messages ahead of the slowest streaming workgroup (batches completed = messages
         // taken + 1); room in the results ring and on the event record
+        {
+            const uint32_t a = w2_uni(fc_rdone), b = w2_uni(fc_wpub), c = w2_uni(fc_evw); // (they only grow)
+            rdone_seen = a > rdone_seen ? a : rdone_seen;
+            wpub_seen = b > wpub_seen ? b : wpub_seen;
+            evw_seen = c > evw_seen ? c : evw_seen;
+        }
         if (seq + 6u > (uint32_t)RS_MSG && !wait_seen(rdone_seen, S_RDONE, seq + 6u - (uint32_t)RS_MSG)) break;
         if (Cn + B > W2_RR && !wait_seen(wpub_seen, S_WPUB, Cn + B - W2_RR)) break;
         if (evn + 2u > W2_EV && !wait_seen(evw_seen, S_EVW, evn + 2u - W2_EV)) break;
+        lap(2);
         ++seq;
         ++n_rounds;
         if (lane == 0) {
@@ -770,9 +792,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         const bool round_trip = is_event && !pivot;
         if (round_trip) ++nev;
         // (behind the message: what only the record needs)
-        const uint32_t qms = (found ? qpos : C) & mrmask;
-        const double mq_v = sh.mave[qms], sq_v = sh.mstd[qms], gsq_v = MISS ? sh.gsum[qms] : 0.0, nmq_v = MISS ? sh.nmis[qms] : 0.0;
-        const double mq = w2_uni(mq_v), sq = w2_uni(sq_v), gsq = w2_uni(gsq_v), nmq = w2_uni(nmq_v);
+        const double mq = q_mq, sq = q_sq, gsq = q_gsq, nmq = q_nmq; // (came with the candidate's other values; a round without an event records zeros: nobody reads them)
         // the event on record (the consumed positions' numerators are in the results ring: the bound test left them there)
         if (found) {
             if (lane == 0) {
