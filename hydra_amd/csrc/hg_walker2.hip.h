@@ -298,8 +298,11 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         gpa32[r] = gpb32[r] = 0u;
         gpa64[r] = gpb64[r] = 0ull;
     }
-    const uint32_t* const gacc = pr.gacc;
-    const unsigned long long* const gacc64 = pr.gacc64;
+    // (global address space, said so: through a generic pointer the polls are FLAT instructions, which the LDS counter counts as well)
+    typedef const __attribute__((address_space(1))) uint32_t* w2_g32;
+    typedef const __attribute__((address_space(1))) unsigned long long* w2_g64;
+    const w2_g32 gacc = (w2_g32)pr.gacc;
+    const w2_g64 gacc64 = (w2_g64)pr.gacc64;
     uint32_t rno = 0; // records taken
 
     // ---- the decider's own state (wave 0; uniform) ----
@@ -422,7 +425,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                 const unsigned long long t0 = wall_clock64();
                 bool bad = false;
                 if constexpr (MISS) {
-                    const unsigned long long* wp = gacc64 + (size_t)par * RS_NSH * RS_GROW + sl;
+                    const w2_g64 wp = gacc64 + (size_t)par * RS_NSH * RS_GROW + sl;
                     unsigned long long A = 0ull;
                     if (hit) {
                         unsigned long long v[RS_NSH];
@@ -458,7 +461,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                     const double xx = mstd * sq * (((Ad - mq * gsm) - mave * gsq) + (mave * mq) * both);
                     dp = hit ? dp + db * xx : dp;
                 } else {
-                    const uint32_t* wp = gacc + (size_t)par * RS_NSH * RS_GROW + sl;
+                    const w2_g32 wp = gacc + (size_t)par * RS_NSH * RS_GROW + sl;
                     uint32_t A = 0u;
                     if (hit) {
                         uint32_t v[RS_NSH];
