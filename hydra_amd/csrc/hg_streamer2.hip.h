@@ -21,8 +21,8 @@
 // units added to racc (rounded ONCE, from the exact 2^-44 sum), batch counters, Gram terms, messages (hg_resident.hip.h).
 // Build MISS: a second product with A' = (code == 3) gives R = sum of eps over the missing calls by the same digits -- s1' = s1 + 3 R and R
 // travel as before; no gather, no copy of eps in LDS.
-// Numerics: |eps| < 64 is required (standardised phenotypes: |eps| of a few units; a sweep that meets a larger one is refused, error 5,
-// never wrapped) -- eps 2^44 then fits 51 bits ("x + 1.5 2^52" rounds to nearest), a column's exact sum 63.  The quantisation of eps,
+// Numerics: |eps| < 64 is required (< 32 at four tiles per workgroup; standardised phenotypes: |eps| of a few units; a sweep that meets a
+// larger one is refused, error 5, never wrapped) -- eps 2^44 then fits 51 bits ("x + 1.5 2^52" rounds to nearest), a column's exact sum 63.  The quantisation of eps,
 // 2^-45 per individual, adds ~1e-11 to a dot at N = 500 K -- below the 1 / fx_scale (~5e-10) the parts are rounded to anyway.
 // Operand maps checked with random data against integer sums: tools/ubench/mfma_limb_dot.hip.
 #pragma once
@@ -261,7 +261,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
 #pragma unroll
         for (int s = 0; s < ND; ++s) {
             rl_digits(e[s], lo[s], hi[s]);
-            big = big || !(fabs(e[s]) < 64.0);
+            big = big || !(fabs(e[s]) < (T == 4 ? 32.0 : 64.0)); // (a column's exact sum over the workgroup's 1024 T individuals must fit 63 bits: 3 x 1024 T x |eps| 2^44)
         }
         if (big) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
         // 4 x 4 byte transposes: digit j of four individuals in one dword (byte s = individual s of the four)

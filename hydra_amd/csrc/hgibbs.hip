@@ -1353,7 +1353,7 @@ static const char* resident_plan(hgibbs_ctx* h, ResPlan* pl)
     if (T > (uint32_t)RS_TMAX) {
         // four tiles per workgroup: the second form of the streaming workgroups only (eps is 2 T doubles per lane there; the window
         // shrinks to 128 columns to make room for their codes), one rank, no predicted pivots, a residual inside the digits' range
-        const bool four = T <= (uint32_t)RL_TMAX && h->nranks <= 1 && resident_refill(h) == 2;
+        const bool four = T <= (uint32_t)RL_TMAX && h->nranks <= 1 && resident_refill(h) == 2 && (h->res_refill == 2 || h->eps_abs_bound < 16.0); // (half the range of T <= 2)
         if (!four) return T <= (uint32_t)RL_TMAX ? "more than 2048 individuals per compute unit need the second form of the streaming workgroups on one rank (option refill, |eps| < 32)"
                                                   : "more individuals than the compute units hold (4096 each)";
         T = (uint32_t)RL_TMAX;
