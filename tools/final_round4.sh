@@ -26,6 +26,6 @@ python3 tools/res_anatomy.py 62500 200000 5 > $O/${R}_shard_62500_anatomy.txt 2>
 HGIBBS_BENCH_BULK=gloo HGIBBS_BENCH_DEVICE=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 \
     bench.py --gpus 2 --steps 3 --warmup 2 > $O/${R}_c4_two_ranks_one_gpu_rehearsal.json 2> $O/gpus2.err; echo gpus2 done
 bash tools/rehearse_ranks.sh 2 125000 200000 4 > $O/${R}_rehearse_2ranks.txt 2>&1; echo rehearsal done
-for u in valu_rate refill_block refill_col mfma_limb_dot; do timeout -k 5 120 ./tools/ubench/$u > $O/${R}_ubench_$u.txt 2>&1; done; echo ubench done
+for u in valu_rate refill_block refill_col mfma_limb_dot; do [ -x tools/ubench/$u ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip > /dev/null 2>&1; timeout -k 5 120 ./tools/ubench/$u > $O/${R}_ubench_$u.txt 2>&1; done; echo ubench done
 timeout -k 5 120 python3 tools/ars_device_probe.py 2000 > $O/${R}_bw_ars_on_one_device_lane.txt 2>&1; echo ars done
 python3 tools/bsum.py $O/${R}_c4_bench_steps20_warmup5.json $O/${R}_c2_bench.json $O/${R}_c3_bench.json $O/${R}_c4_missing1pct_bench.json $O/${R}_c4_first_walker_bench.json $O/${R}_c4_first_form_bench.json $O/${R}_c4_no_announce_bench.json $O/${R}_c4_missing1pct_first_form_bench.json $O/${R}_c4_pivots_bench.json $O/${R}_c2_first_form_bench.json
