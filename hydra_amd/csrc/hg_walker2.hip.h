@@ -769,6 +769,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
             pivot = qpos + 1u >= Sx || pi - w2_uni(sh.bl_pi[w2_uni(sh.batch[(qpos + 1u) & bmask]) % W2_NB]) < (uint32_t)RS_PMAX;
         // flow control: never more than RS_MSG - 3 messages ahead of the slowest streaming workgroup (batches completed = messages
         // taken + 1); room in the results ring and on the event record
+        lap(6);
         {
             const uint32_t a = w2_uni(fc_rdone), b = w2_uni(fc_wpub), c = w2_uni(fc_evw); // (they only grow)
             rdone_seen = a > rdone_seen ? a : rdone_seen;

@@ -57,4 +57,5 @@ if timing:
     print("percentiles of message in flight (us):", np.percentile((S0 - W0)[ev] / 100.0, [5, 50, 95]).round(2), " of atomics -> walker:", np.percentile((W1 - S2)[ev] / 100.0, [5, 50, 95]).round(2))
 if timing and s.get("walker") == 2:
     print("clock read: %.3f us each (64 reads back to back)" % (t[7] / 100.0 / 64.0))
-    print("walker 2, per round (us): loop top %.2f  absorb %.2f  wait dots %.2f  bound test %.2f  exact %.2f  message+bookkeeping %.2f  wait Gram %.2f" % (us(t[6]), us(t[5]), us(t[0]), us(t[2]), us(t[3]), us(t[4]), us(t[1])))
+    print("walker 2, per round (us): absorb %.2f  wait Gram / answers %.2f  wait dots %.2f  exact decision %.2f  what the round is (early advance, counts) %.2f  flow control %.2f  message+bookkeeping %.2f"
+          % (us(t[5]), us(t[1]), us(t[0]), us(t[3]), us(t[6]), us(t[2]), us(t[4])))
