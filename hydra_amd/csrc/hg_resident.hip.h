@@ -74,6 +74,12 @@ __host__ __device__ inline uint32_t rs_msg_check(uint32_t seq, uint32_t lo, uint
     x ^= x >> 16;
     return x & 0xffffu;
 }
+// where the window that starts at position C ends
+__host__ __device__ inline uint32_t rs_window_end(uint32_t C, uint32_t B, uint32_t M, uint32_t mask)
+{
+    const uint32_t e = (C + B) & ~mask;
+    return e < M ? e : M;
+}
 __host__ __device__ inline uint32_t rs_msg_word0(uint32_t kf, uint32_t ncons, uint32_t seq, uint32_t lo, uint32_t hi) { return (kf << 28) | (rs_msg_check(seq, lo, hi) << 12) | ncons; }
 
 struct ResState { // device -> host, written by the walker at the end of the sweep
@@ -133,6 +139,8 @@ struct ResParams {
     int pivots; // 1: Gram terms with predicted pivots are taken when a column is streamed (messages RS_PIVOT need no round trip)
     int tune;   // experiments (option res_tune): bits 0-1: priority of the younger wave of each SIMD (waves 4 .. 7) in the refill
     int early_advance; // second walker: a walk that has run out of dots moves the window on at once (a message that only advances) when at least this many positions have passed (0: it waits)
+    uint32_t wend_mask; // 15 (second walker, B >= 32): the window ends at a multiple of sixteen positions -- min((C + B) & ~15, M) -- so that the
+                        // streaming workgroups' second form admits every group of sixteen columns in ONE round (else 0: the window is C + B)
     int announce; // second walker: 1: an event that is certain (a marker with a non-zero effect) is announced to the streaming workgroups before its draw (RS_ANNOUNCE)
     int walker; // 2: the second walker (hg_walker2.hip.h: one wave walks the chain, the others serve it), else the first
     const uint32_t* pred; // the sweep positions whose marker has a non-zero effect at sweep start (predicted events), ascending, then 16 sentinels 0xffffffff
@@ -666,7 +674,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
         const uint32_t Cn = ann ? C : C + ncons;
-        const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
+        const uint32_t Sn = rs_window_end(Cn, B, M, p.wend_mask);
         const uint32_t nnew = Sn - Sx;
         uint32_t count_w = (Sn > (uint32_t)wave ? (Sn - (uint32_t)wave + 7u) / 8u : 0u) - nk; // this wave's positions in [Sx, Sn)
         cols_landed(); // issued at the end of the last round: nothing to wait for (and no Gram atomic in flight yet; behind an announcement they went out a draw ago)

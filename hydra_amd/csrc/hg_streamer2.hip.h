@@ -402,7 +402,7 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
         if (DBG && wg == 0 && tid == 0) p.progress[1] = ((unsigned long long)seq << 8) | 1u;
         const uint32_t q = C + ncons - 1u;
         const uint32_t Cn = ann ? C : C + ncons;
-        const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
+        const uint32_t Sn = rs_window_end(Cn, B, M, p.wend_mask);
         const uint32_t nnew = Sn - Sx;
         cols_landed(); // issued at the end of the last round: nothing to wait for
 

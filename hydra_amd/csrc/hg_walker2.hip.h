@@ -238,7 +238,8 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     const Walk2Lds sh = walk2_lds(B); \
     const uint32_t cntG[2] = {W / nsh + (W % nsh ? 1u : 0u), W / nsh}; \
     const uint32_t cntR[2] = {W / rsh + (W % rsh ? 1u : 0u), W / rsh}; \
-    const uint32_t Sx0 = (B < M) ? B : M; \
+    const uint32_t wend_mask = pr.wend_mask; \
+    const uint32_t Sx0 = rs_window_end(0u, B, M, wend_mask); \
     const uint32_t m0 = MR < M ? MR : M; \
     auto stage_meta = [&](uint32_t j) { \
         const uint32_t ms = j & mrmask; \
@@ -758,7 +759,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
         // ---- the message: an event at qpos, or a round that only moves the window on ----
         const uint32_t ncons = found ? qpos - C + 1u : (early ? Fs - C : Sx - C);
         const uint32_t Cn = C + ncons;
-        const uint32_t Sn = (Cn + B < M) ? Cn + B : M;
+        const uint32_t Sn = rs_window_end(Cn, B, M, wend_mask);
         const double dbeta = found ? q_bold - q_bnew : 0.0;
         const bool changed = found && dbeta != 0.0;
         const bool is_event = changed || announced; // (announced and drawn the very same effect again: an event that changes nothing -- the Gram terms have been asked for)

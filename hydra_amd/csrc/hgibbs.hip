@@ -161,6 +161,7 @@ struct hgibbs_ctx {
     bool res_not_resident = false; // a resident grid was found partly resident (another process on the device): engine 0 means the batch engine from then on
     int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_announce = 1;     // option announce (ResParams::announce)
+    int res_wend = 1;         // option window_end16 (ResParams::wend_mask)
     double eps_abs_bound = 0.0; // (sum of eps^8)^(1/8) >= max |eps| as of the last reduce_eps_all
     int res_refill = 0;       // option refill: the streaming workgroups' form -- 1 first (hg_resident.hip.h: fused multiply-adds), 2 second (hg_streamer2.hip.h: integer matrix products), 0 auto
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
@@ -1247,6 +1248,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "refill")) {
         if (value < 0 || value > 2) return fail("refill must be 0 (auto), 1 (fused multiply-adds) or 2 (integer matrix products)");
         h->res_refill = (int)value;
+    } else if (!std::strcmp(name, "window_end16")) {
+        h->res_wend = value != 0;
     } else if (!std::strcmp(name, "announce")) {
         h->res_announce = value != 0;
     } else if (!std::strcmp(name, "res_tune")) {
@@ -1533,6 +1536,7 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.tune = h->res_tune;
     p.early_advance = h->res_early;
     p.announce = h->res_announce;
+    p.wend_mask = (p.walker == 2 && pl.B >= 32u && h->res_wend) ? 15u : 0u;
     {
         // the predicted events of this sweep, in sweep order (read by the streaming workgroups and by the walker)
         const uint32_t nchunk = (h->M + PRED_CHUNK - 1) / PRED_CHUNK;
