@@ -161,6 +161,8 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
  *                   first walker, 2 the second (hg_walker2.hip.h; the call fails where it does not apply)
  *   announce        second walker: 1 (default) = an event that is certain (a marker whose effect is non-zero) is announced before
  *                   its draw, so that its Gram terms travel meanwhile
+ *   window_end16    second walker: 1 (default) = the window ends at a multiple of sixteen positions (the second form of the streaming
+ *                   workgroups then takes every group of sixteen columns once); 0 = at exactly `window` columns behind the cursor
  *   early_advance   second walker: a walk that runs out of dots moves the window on at once when at least this many positions have
  *                   passed (default 24; 0 = it waits)
  *   res_timeout_ms  resident engine: longest wait of any workgroup for another before the sweep is abandoned with an error
