@@ -54,6 +54,12 @@ if timing:
     f = lambda x: "%.2f" % (np.mean(x) / 100.0)
     print("per message with an update (us, n=%d): message in flight %s | update %s | gram %s | stream %s | Gram atomics -> walker has them %s | walker: collect done -> next message %s | consumed %.1f"
           % (ev.sum(), f((S0 - W0)[ev]), f((S1 - S0)[ev]), f((S2 - S1)[ev]), f((S3 - S2)[ev]), f((W1 - S2)[ev]), f((W2 - W1)[ev]), np.mean(NC[ev])))
+    # how long a round lasts, by what its message carried (stamps of consecutive messages)
+    idn = (idx + 1) % 4096
+    dur = (tr[0][idn] - W0) / 100.0
+    okd = (dur > 0) & (dur < 1000)
+    print("round = message to next message (us): rounds with an update %.2f (n=%d, %.1f positions), rounds that only advance %.2f (n=%d, %.1f positions)"
+          % (np.mean(dur[ev & okd]), (ev & okd).sum(), np.mean(NC[ev & okd]), np.mean(dur[~ev & okd]) if (~ev & okd).any() else 0.0, (~ev & okd).sum(), np.mean(NC[~ev & okd]) if (~ev & okd).any() else 0.0))
     print("percentiles of message in flight (us):", np.percentile((S0 - W0)[ev] / 100.0, [5, 50, 95]).round(2), " of atomics -> walker:", np.percentile((W1 - S2)[ev] / 100.0, [5, 50, 95]).round(2))
 if timing and s.get("walker") == 2:
     print("clock read: %.3f us each (64 reads back to back)" % (t[7] / 100.0 / 64.0))
