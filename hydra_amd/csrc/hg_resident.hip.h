@@ -74,6 +74,13 @@ __host__ __device__ inline uint32_t rs_msg_check(uint32_t seq, uint32_t lo, uint
     x ^= x >> 16;
     return x & 0xffffu;
 }
+// A workgroup's add to a raw-dot word (racc, racc2) carries its arrival in the top byte, as the Gram words do: the low 56 bits are the
+// fixed-point sum (|total| < 2^52 by the scale's bound: it cannot reach the count), the top byte counts the workgroups that have added -- a
+// reader takes the difference to what it saw last (the words only ever grow), and a sum that is short of an arrival is never accepted,
+// whatever the batch counters say.
+constexpr unsigned long long RS_RONE = 1ull << 56;
+__host__ __device__ inline unsigned long long rs_raw_value(unsigned long long d) { return (unsigned long long)((long long)(d << 8) >> 8); } // the sum, sign-extended
+__host__ __device__ inline uint32_t rs_raw_count(unsigned long long d) { return (uint32_t)((d - rs_raw_value(d)) >> 56) & 0xffu; }
 // where the window that starts at position C ends
 __host__ __device__ inline uint32_t rs_window_end(uint32_t C, uint32_t B, uint32_t M, uint32_t mask)
 {
@@ -907,7 +914,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
                 const unsigned long long fr = rlds[t];
                 rlds[t] = 0ull; // (the next round's lanes add behind this round's last barrier)
                 if (!(fabs((double)(long long)fr) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range: the sweep is refused, not wrapped
-                if (fr) __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), fr, HG_RLX_AGENT);
+                __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), fr + RS_RONE, HG_RLX_AGENT);
             } else {
                 const double* pp = part + t * 8u;
                 s1 = pp[0];
@@ -917,7 +924,7 @@ __device__ __forceinline__ void res_streamer(const ResParams& p, unsigned char* 
             const double xs = s1 * p.fx_scale;
             if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range (or not finite): the sweep is refused, not wrapped
             const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
-            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
+            __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx + RS_RONE, HG_RLX_AGENT);
         }
         // Only the waves that sent something wait for their atomics to be performed (~0.6 us); the last of them to be through counts the
         // batch in for the walker.  The others go straight on to the next message -- which a wave polls that has nothing to drain -- so the
@@ -1224,8 +1231,12 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             atomicMin(&sh.fl[WF_FMIN], j);
             return;
         }
-        unsigned long long tot, totR = 0ull;
+        unsigned long long tot, totR = 0ull, now1 = 0ull;
         if (p.nranks > 1) { // this rank's part was taken by push_raw (same thread, same pass); the peers' parts: two self-validating words each
+            if (!sh.fpush[slot]) { // (this rank's own part was short of an arrival: next pass)
+                atomicMin(&sh.fl[WF_FMIN], j);
+                return;
+            }
             const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
             if constexpr (MISS) { // (the peers' parts of R first: the four words of a position are checked together)
                 unsigned long long o2[RX_MAXR][2];
@@ -1275,8 +1286,13 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             unsigned long long now = 0ull;
 #pragma unroll
             for (int s = 0; s < RS_RSH; ++s) now += w[s];
-            tot = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic)
-            sh.rprev[j % RS_RB] = now;
+            const unsigned long long d = now - sh.rprev[j % RS_RB]; // what this position's batch added (wrapping 64-bit arithmetic), every workgroup's arrival counted
+            if (rs_raw_count(d) != (p.W & 0xffu)) { // (the batch counter said "complete": an add that is not there yet is waited for, never left out)
+                atomicMin(&sh.fl[WF_FMIN], j);
+                return;
+            }
+            now1 = now; // (kept as "seen" below, in build MISS only when the second word is complete as well)
+            tot = rs_raw_value(d);
         }
         double s1 = (double)(long long)tot * p.fx_unscale;
         double s2 = p.eps_sum;
@@ -1291,11 +1307,17 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             unsigned long long now2 = 0ull;
 #pragma unroll
             for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
-            const unsigned long long tot2 = now2 - sh.rprev2[j % RS_RB];
+            const unsigned long long d2 = now2 - sh.rprev2[j % RS_RB];
+            if (rs_raw_count(d2) != (p.W & 0xffu)) {
+                atomicMin(&sh.fl[WF_FMIN], j);
+                return;
+            }
             sh.rprev2[j % RS_RB] = now2;
+            const unsigned long long tot2 = rs_raw_value(d2);
             s1 = (double)(long long)(tot - 3ull * tot2) * p.fx_unscale; // (the streamed dot weighs a missing call 3: s1' = s1 + 3 R, exact integers)
             s2 -= (double)(long long)tot2 * p.fx_unscale;
         }
+        if (p.nranks <= 1) sh.rprev[j % RS_RB] = now1;
         sh.dpr[slot] = sh.mstd[slot] * (s1 - sh.mave[slot] * s2);
         // the column's Gram terms with its batch's pivots (those in front of it), and the corrections of the pivots that have fired since
         // the column was streamed
@@ -1346,9 +1368,9 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
         unsigned long long now = 0ull;
 #pragma unroll
         for (int s = 0; s < RS_RSH; ++s) now += w[s];
-        const unsigned long long tot = now - sh.rprev[j % RS_RB];
-        sh.rprev[j % RS_RB] = now;
-        sh.rloc[slot] = tot;
+        const unsigned long long d = now - sh.rprev[j % RS_RB];
+        if (rs_raw_count(d) != (p.W & 0xffu)) return; // (an add that has not been performed yet: taken in a later pass -- fpush stays clear)
+        const unsigned long long tot = rs_raw_value(d);
         unsigned long long tot2 = 0ull;
         if constexpr (MISS) {
             unsigned long long* base2 = p.racc2 + (j % RS_RB);
@@ -1358,10 +1380,14 @@ __device__ __attribute__((noinline)) void res_walker(const ResParams& p, unsigne
             unsigned long long now2 = 0ull;
 #pragma unroll
             for (int s = 0; s < RS_RSH; ++s) now2 += w2[s];
-            tot2 = now2 - sh.rprev2[j % RS_RB];
+            const unsigned long long d2 = now2 - sh.rprev2[j % RS_RB];
+            if (rs_raw_count(d2) != (p.W & 0xffu)) return;
+            tot2 = rs_raw_value(d2);
             sh.rprev2[j % RS_RB] = now2;
             sh.rloc2[slot] = tot2;
         }
+        sh.rprev[j % RS_RB] = now;
+        sh.rloc[slot] = tot;
         const unsigned long long tag = rx_rtag(p.sweep_id, sh.batch[slot]);
         for (int r = 0; r < p.nranks; ++r)
             if (r != p.rank) {

@@ -545,12 +545,12 @@ __device__ __forceinline__ void res_streamer_limb(const ResParams& p, unsigned c
                     const double xr = (double)tot2 * unit;
                     if (!(fabs(xr) < 2.2e15)) atomicMax(&p.state->error, 5u);
                     const long long fr = __double_as_longlong(xr + MAGIC) - __double_as_longlong(MAGIC);
-                    if (fr) __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr, HG_RLX_AGENT);
+                    __hip_atomic_fetch_add(p.racc2 + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fr + RS_RONE, HG_RLX_AGENT);
                 }
                 const double xs = (double)tot * unit;
                 if (!(fabs(xs) < 2.2e15)) atomicMax(&p.state->error, 5u); // out of the fixed-point range: the sweep is refused, not wrapped
                 const long long fx = __double_as_longlong(xs + MAGIC) - __double_as_longlong(MAGIC);
-                __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx, HG_RLX_AGENT);
+                __hip_atomic_fetch_add(p.racc + (size_t)(wg % p.rsh) * RS_RB + ((Sx + t) % RS_RB), (unsigned long long)fx + RS_RONE, HG_RLX_AGENT); // (the arrival in the top byte)
             }
             count_due = true;
             if (last) { // (no message follows: the count goes out here)

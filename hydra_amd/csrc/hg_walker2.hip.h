@@ -929,19 +929,20 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
             t_idle = wall_clock64();
             continue;
         }
-        if (done <= fb) {
-            poll_done();
-            if (done <= fb) {
-                if (wall_clock64() - t_idle > timeout) {
-                    if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                continue;
+        // The raw-dot words say themselves when they are complete (every workgroup's arrival in the top byte): the announced positions are
+        // read as soon as they are announced, and what is complete is folded -- no wait for the batch counters (they lag the adds by the
+        // streaming workgroups' drain and one more trip; they still feed the decider's flow control).  With predicted pivots the pivot words
+        // have no count of their own: there the batch counter gates as before.
+        poll_done();
+        if (pivots && done <= fb) {
+            if (wall_clock64() - t_idle > timeout) {
+                if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
+                break;
             }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
         }
-        // up to 128 positions from Ff on whose batch is complete (batches are in position order: a prefix), two to a lane, all their loads
-        // in flight together: one round trip for a refill batch of the usual size
+        // up to 128 positions from Ff on, two to a lane, all their loads in flight together: one round trip for a refill batch of the usual size
         bool okv[2], pivv[2];
         uint32_t jv[2];
         unsigned long long w[2][RS_RSH], w2[2][RS_RSH], wp[2][RS_RSH][2];
@@ -951,7 +952,7 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
             jv[h] = j;
             uint32_t bt = fb;
             while (bt < sq && j >= sh.bl_sn[bt % W2_NB]) ++bt; // (per lane: the positions may span a few batches)
-            okv[h] = j < sx && bt < done && (h == 0 || B >= 128u); // (two positions of a pass never share a window slot)
+            okv[h] = j < sx && (!pivots || bt < done) && (h == 0 || B >= 128u); // (two positions of a pass never share a window slot)
             const uint32_t np = sh.bl_np[bt % W2_NB];
             pivv[h] = okv[h] && np && sh.bl_p0[bt % W2_NB] < j; // a pivot in front of the column: its terms were sent
         }
@@ -973,23 +974,47 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
                 }
             }
         }
+        // which of them are complete: the difference to what was seen last carries W arrivals (both words in build MISS); positions are
+        // folded in order, so only the complete PREFIX counts (a later position that happens to be complete waits for its turn)
+        unsigned long long nowv[2], now2v[2], dv[2], d2v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t rr = jv[h] % RS_RB;
+            nowv[h] = now2v[h] = 0ull;
+#pragma unroll
+            for (int s = 0; s < RS_RSH; ++s) nowv[h] += w[h][s];
+            dv[h] = nowv[h] - sh.rprev[rr];
+            bool full = rs_raw_count(dv[h]) == (W & 0xffu);
+            d2v[h] = 0ull;
+            if constexpr (MISS) {
+#pragma unroll
+                for (int s = 0; s < RS_RSH; ++s) now2v[h] += w2[h][s];
+                d2v[h] = now2v[h] - sh.rprev2[rr];
+                full = full && rs_raw_count(d2v[h]) == (W & 0xffu);
+            }
+            okv[h] = okv[h] && full;
+        }
+        {
+            const unsigned long long b0 = __ballot(okv[0]);
+            const uint32_t n0p = b0 == ~0ull ? (uint32_t)WAVE : (uint32_t)(__ffsll((long long)~b0) - 1); // leading complete positions of the first 64
+            okv[0] = okv[0] && (uint32_t)lane < n0p;
+            const unsigned long long b1 = n0p == (uint32_t)WAVE ? __ballot(okv[1]) : 0ull;
+            const uint32_t n1p = b1 == ~0ull ? (uint32_t)WAVE : (uint32_t)(__ffsll((long long)~b1) - 1);
+            okv[1] = okv[1] && n0p == (uint32_t)WAVE && (uint32_t)lane < n1p;
+            pivv[0] = pivv[0] && okv[0];
+            pivv[1] = pivv[1] && okv[1];
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (okv[h]) {
                 const uint32_t j = jv[h], slot = j & bmask, rr = j % RS_RB;
-                unsigned long long now = 0ull;
-#pragma unroll
-                for (int s = 0; s < RS_RSH; ++s) now += w[h][s];
-                const unsigned long long tot = now - sh.rprev[rr]; // what this position's batch added (wrapping 64-bit arithmetic)
-                sh.rprev[rr] = now;
+                const unsigned long long tot = rs_raw_value(dv[h]); // what this position's batch added (wrapping 64-bit arithmetic, the arrivals taken off)
+                sh.rprev[rr] = nowv[h];
                 double s1 = (double)(long long)tot * fx_unscale;
                 double s2 = eps_sum;
                 if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R; the streamed dot weighs a missing call 3: s1' = s1 + 3 R
-                    unsigned long long now2 = 0ull;
-#pragma unroll
-                    for (int s = 0; s < RS_RSH; ++s) now2 += w2[h][s];
-                    const unsigned long long tot2 = now2 - sh.rprev2[rr];
-                    sh.rprev2[rr] = now2;
+                    const unsigned long long tot2 = rs_raw_value(d2v[h]);
+                    sh.rprev2[rr] = now2v[h];
                     s1 = (double)(long long)(tot - 3ull * tot2) * fx_unscale; // (exact: integers)
                     s2 -= (double)(long long)tot2 * fx_unscale;
                 }
@@ -1014,6 +1039,14 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
         }
         const uint32_t n0 = (uint32_t)__popcll(__ballot(okv[0]));
         const uint32_t n = n0 + (n0 == (uint32_t)WAVE ? (uint32_t)__popcll(__ballot(okv[1])) : 0u);
+        if (n == 0u) { // (the first announced position is still short of an arrival)
+            if (wall_clock64() - t_idle > timeout) {
+                if (lane == 0) w2_st(sh.sw + S_ABORT, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
         w2_lds_done();
         Ff += n;
         if (lane == 0) w2_st(sh.sw + S_FPUB, Ff);
