@@ -1432,7 +1432,9 @@ static int resident_probe(hgibbs_ctx* h, const ResPlan& pl)
     p.M = 0xffffffffu; // (probe: see k_sweep_resident)
     p.state = h->res_state;
     p.progress = h->res_progress;
-    p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 0.1) * 1e8);
+    // (the ranks launch their probes within the skew of a host-side all-reduce -- but a rank's first launch of the kernel may load its code
+    // object first: the peers' handshake is given a second, not the 0.1 s of a grid's own rendezvous)
+    p.rdv_timeout = (unsigned long long)(std::min(h->res_timeout_s, 1.0) * 1e8);
     p.nranks = h->nranks > 1 ? h->nranks : 1;
     p.rank = h->nranks > 1 ? h->rank : 0;
     for (int r = 0; r < RX_MAXR; ++r) p.mbox[r] = (h->nranks > 1 && r < h->nranks) ? (unsigned char*)h->peer_base[r] + MBOX_RES_OFF : nullptr;
