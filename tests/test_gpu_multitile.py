@@ -171,6 +171,23 @@ def test_resident_two_tiles_64_workgroups_vs_oracle(oracle, miss_cols, walker):
     d.close()
 
 
+@pytest.mark.parametrize("N,T,miss_cols", [(500000, 2, 0.0), (500000, 2, 0.5), (1000000, 4, 0.0)])
+def test_headline_geometry_vs_oracle(oracle, N, T, miss_cols):
+    """The headline's own geometry against the ORACLE, directly: N = 500 000 individuals on the whole device -- 245 streaming workgroups of
+    two tiles and the walker, default options -- with few enough markers (256) for the oracle to follow in seconds; clean, and with 2 %
+    missing calls in half of the columns (build MISS).  And a million individuals: four tiles per workgroup."""
+    M = 256 if N <= 500000 else 160
+    bed, y = _case(M, N, miss_cols, seed=17)
+    _run_vs_oracle(oracle, bed, y, N, {}, iters=3)
+    d = capi.Device(0)
+    d.load_bed(bed, N)
+    ch = capi.Chain(d, y, seed=31, shuffle=1)
+    ch.iterate()
+    ss = d.sweep_stats()
+    assert ss["engine"] == 2 and ss["tiles_per_workgroup_max"] == T and ss["walker"] == 2 and ss["refill"] == 2
+    d.close()
+
+
 # ---------------------------------------------------------------------------
 # sharded: two processes on one GPU, more than 49 152 individuals per rank (several tile groups per workgroup on
 # every rank), each replica against the oracle
