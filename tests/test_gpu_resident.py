@@ -5,6 +5,8 @@ Same bar as tests/test_gpu_parity.py: marker order, mixture-component indices, c
 of updates exact; beta, acum, the hyper-parameters and the residual within 1e-9 (the dots are summed in a different,
 fixed order -- here even as integers -- than the oracle's sequential loop).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -239,7 +241,7 @@ def test_refused_where_it_does_not_apply(oracle):
         ch.iterate()
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(int(os.environ.get("HG_RANDOM_CASES", "24"))))
 def test_random_configurations_match_the_oracle(oracle, case):
     """Seeded random combinations of shape (ragged N, M), mixture size, groups, share of columns with missing calls and their rate,
     causal share, window, compute units in use (one or two tiles per workgroup) and predicted pivots: four iterations against the
@@ -261,6 +263,19 @@ def test_random_configurations_match_the_oracle(oracle, case):
         opts["res_cus"] = (tiles + 1) // 2 + 1  # two tiles per workgroup
     if missing_cols == 0.0 and rng.random() < 0.3:
         opts["pivots"] = 1
+    if case >= 24:  # (HG_RANDOM_CASES > 24: a longer campaign over the knobs of round 4 as well -- forms of the streaming workgroups, walkers,
+        # announcements, where the window ends, early advances, four tiles per workgroup; the first 24 cases stay what they were)
+        if rng.random() < 0.3:
+            opts["refill"] = 1
+        if rng.random() < 0.25:
+            opts["walker"] = 1
+        if rng.random() < 0.3:
+            opts["announce"] = 0
+        if rng.random() < 0.3:
+            opts["window_end16"] = 0
+        opts["early_advance"] = int(rng.choice([0, 8, 24, 64]))
+        if tiles >= 8 and opts.get("refill", 2) == 2 and "pivots" not in opts and rng.random() < 0.4:
+            opts["res_cus"] = (tiles + 3) // 4 + 1  # four tiles per workgroup
     run_vs_oracle(oracle, M, N, iters=4, groups=groups, mS=mS, opts=opts, seed=int(rng.integers(1, 1 << 30)), causal_frac=float(rng.choice([0.01, 0.05, 0.3])),
                   missing_rate=0.03 if missing_cols > 0.0 else 0.0, missing_cols=missing_cols)
 
