@@ -187,6 +187,55 @@ def test_two_ranks_whose_grids_cannot_share_the_device_finish_on_the_batch_engin
     assert tol(np.concatenate([r[5] for r in res]), ref.arr("eps"))
 
 
+@pytest.mark.parametrize("case", range(int(os.environ.get("HG_RANDOM_RANK_CASES", "3"))))
+def test_random_sharded_configurations_match_the_oracle(oracle, case):
+    """Seeded random sharded runs of the resident engine (2 to 4 processes sharing device 0, ragged shards, windows, compute units per
+    rank, missing calls) against the oracle on the whole data; HG_RANDOM_RANK_CASES lengthens the campaign."""
+    import torch.multiprocessing as mp
+    import orc
+    from hydra_amd import synth
+    rng = np.random.default_rng(9100 + case)
+    world = int(rng.choice([2, 2, 3, 4]))
+    N = int(rng.choice([9000, 21000, 30011, 52000]))
+    M = int(rng.integers(120, 500))
+    miss = float(rng.choice([0.0, 0.0, 0.02]))
+    opts = {"engine": 2, "window": int(rng.choice([32, 64, 128, 256]))}
+    if rng.random() < 0.4:
+        opts["res_cus"] = int(rng.choice([5, 9, 14]))
+    if rng.random() < 0.3:
+        opts["refill"] = 1
+    geno = synth.make_genotypes(M, N, seed=200 + case, missing_rate=miss)
+    y, _ = synth.make_phenotype(geno, seed=300 + case, causal_frac=float(rng.choice([0.02, 0.1])))
+    bed = synth.pack_bed_columns(geno)
+    iters = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bed, y, N, iters, opts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    what = "case %d: world %d N %d M %d miss %g %r" % (case, world, N, M, miss, opts)
+    if all(len(r) == 2 and "does not apply" in r[1] for r in res):  # (a shard too large for the compute units drawn: every rank refuses alike)
+        pytest.skip("resident engine refused: " + what)
+    for r in res:
+        assert len(r) == 10, "rank %s failed: %s (%s)" % (r[0], r[1], what)
+    res.sort(key=lambda r: r[0])
+    if res[0][7] != [2]:  # (a shard that does not fit the compute units asked for: the ranks agreed on the batch engine -- not this test's subject)
+        pytest.skip("resident engine refused: " + what)
+    ref = orc.Chain(oracle, bed, N, y, seed=1222)
+    for _ in range(iters):
+        ref.iterate()
+    tol = lambda a, b: np.all(np.abs(np.asarray(a) - np.asarray(b)) <= 1e-9 * np.maximum(1.0, np.abs(np.asarray(b))))
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]), what
+    assert np.array_equal(res[0][2], ref.arr("components")), what
+    assert tol(res[0][1], ref.arr("beta")) and tol(res[0][3], ref.sigmaE), what
+    assert tol(np.concatenate([r[5] for r in res]), ref.arr("eps")), what
+
+
 def _worker_bw(rank, world, port, bed, y, fail, X, N, iters, q):
     import torch
     import torch.distributed as dist
