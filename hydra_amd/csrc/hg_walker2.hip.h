@@ -103,6 +103,9 @@ enum { RT_EXTEND = 0, RT_ADVANCE = 1, RT_PIVOT = 2, RT_EVENT = 3, RT_END = 4 };
     X(unsigned long long, rprev, (size_t)RS_RB) /* the accumulators' sums as last seen (they only ever grow) */                               \
     X(unsigned long long, rprev2, (size_t)RS_RB)                                                                                              \
     X(unsigned long long, pprev, (size_t)2 * RS_RB)                                                                                           \
+    X(unsigned long long, rloc, Bz)       /* several ranks: this rank's part of the slot's raw dot (pushed to the peers; the dot needs theirs) */ \
+    X(unsigned long long, rloc2, Bz)      /*   (build MISS) the same for R */                                                                 \
+    X(uint32_t, rpushed, Bz)              /*   ... has been taken and pushed */                                                               \
     X(double, pf_val, (size_t)RS_PFIRE * 3) /* fired pivots: (dbeta, mave, mstd) */                                                           \
     X(uint32_t, ans, (size_t)W2_NCH * 4)  /* the chain waves' answers: {candidate mask (two words), records answered, -}, 16 bytes each */        \
     X(uint32_t, mt, (size_t)W2_RING)      /* untempered generator words */                                                                    \
@@ -239,6 +242,8 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
     const uint32_t cntG[2] = {W / nsh + (W % nsh ? 1u : 0u), W / nsh}; \
     const uint32_t cntR[2] = {W / rsh + (W % rsh ? 1u : 0u), W / rsh}; \
     const uint32_t wend_mask = pr.wend_mask; \
+    const int nranks = pr.nranks, rank = pr.rank; \
+    const unsigned long long sweep_id = pr.sweep_id; \
     const uint32_t Sx0 = rs_window_end(0u, B, M, wend_mask); \
     const uint32_t m0 = MR < M ? MR : M; \
     auto stage_meta = [&](uint32_t j) { \
@@ -456,6 +461,36 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                             gpb64[r] = par ? v[r] : pb;
                         }
                     }
+                    if (nranks > 1 && hit && !bad) {
+                        // several ranks: the 56-bit sums cross as two words each, tag << 32 | half (tag = 1 | sweep | event: self-validating), by window slot
+                        const unsigned long long tag = (0x80000000ull | ((sweep_id & 0x7full) << 24) | (unsigned long long)(w2_uni(rc[R_NEV]) & 0xffffffu)) << 32;
+                        for (int r = 0; r < nranks; ++r)
+                            if (r != rank) {
+                                unsigned long long* w = rx_gbox(pr.mbox[r], rank, par) + 2u * sl;
+                                __hip_atomic_store(w, tag | (A & 0xffffffffull), HG_RLX_SYSTEM);
+                                __hip_atomic_store(w + 1, tag | (A >> 32), HG_RLX_SYSTEM);
+                            }
+                        for (;;) {
+                            bool all = true;
+                            unsigned long long add = 0ull;
+                            for (int r = 0; r < nranks; ++r)
+                                if (r != rank) {
+                                    const unsigned long long* w = rx_gbox(pr.mbox[rank], r, par) + 2u * sl;
+                                    const unsigned long long o0 = __hip_atomic_load(w, HG_RLX_SYSTEM), o1 = __hip_atomic_load(w + 1, HG_RLX_SYSTEM);
+                                    all = all && (o0 >> 32) == (tag >> 32) && (o1 >> 32) == (tag >> 32);
+                                    add += (o1 << 32) | (o0 & 0xffffffffull);
+                                }
+                            if (all) {
+                                A += add;
+                                break;
+                            }
+                            if (wall_clock64() - t0 > timeout || aborted()) {
+                                bad = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
                     const double gsq = *(const W2_LDS double*)(rc + R_GSQ), nmq = *(const W2_LDS double*)(rc + R_NMQ);
                     const double Ad = (double)A * (1.0 / (double)(1ull << RS_GFX));
                     const double both = n_total - nms - nmq; // + X: calls present in both columns
@@ -490,6 +525,32 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                             A += d & RS_LOW;
                             gpa32[r] = par ? pa : v[r];
                             gpb32[r] = par ? v[r] : pb;
+                        }
+                    }
+                    if (nranks > 1 && hit && !bad) {
+                        // several ranks: this rank's sum goes to every peer's mailbox, the peers' arrive in mine -- sweep << 48 | event << 24 | sum, one
+                        // 8-byte store, self-validating; by window slot
+                        const unsigned long long tag = (sweep_id << 48) | ((unsigned long long)(w2_uni(rc[R_NEV]) & 0xffffffu) << 24);
+                        for (int r = 0; r < nranks; ++r)
+                            if (r != rank) __hip_atomic_store(rx_gbox(pr.mbox[r], rank, par) + 2u * sl, tag | (unsigned long long)A, HG_RLX_SYSTEM);
+                        for (;;) {
+                            bool all = true;
+                            uint32_t add = 0u;
+                            for (int r = 0; r < nranks; ++r)
+                                if (r != rank) {
+                                    const unsigned long long o = __hip_atomic_load(rx_gbox(pr.mbox[rank], r, par) + 2u * sl, HG_RLX_SYSTEM);
+                                    all = all && (o >> 24) == (tag >> 24);
+                                    add += (uint32_t)o & RS_LOW;
+                                }
+                            if (all) {
+                                A += add;
+                                break;
+                            }
+                            if (wall_clock64() - t0 > timeout || aborted()) {
+                                bad = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
                         }
                     }
                     const double xx = mstd * sq * ((double)A - n_total * (mave * mq));
@@ -944,7 +1005,7 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
         }
         // up to 128 positions from Ff on, two to a lane, all their loads in flight together: one round trip for a refill batch of the usual size
         bool okv[2], pivv[2];
-        uint32_t jv[2];
+        uint32_t jv[2], btv[2];
         unsigned long long w[2][RS_RSH], w2[2][RS_RSH], wp[2][RS_RSH][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -952,6 +1013,7 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
             jv[h] = j;
             uint32_t bt = fb;
             while (bt < sq && j >= sh.bl_sn[bt % W2_NB]) ++bt; // (per lane: the positions may span a few batches)
+            btv[h] = bt;
             okv[h] = j < sx && (!pivots || bt < done) && (h == 0 || B >= 128u); // (two positions of a pass never share a window slot)
             const uint32_t np = sh.bl_np[bt % W2_NB];
             pivv[h] = okv[h] && np && sh.bl_p0[bt % W2_NB] < j; // a pivot in front of the column: its terms were sent
@@ -976,21 +1038,67 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
         }
         // which of them are complete: the difference to what was seen last carries W arrivals (both words in build MISS); positions are
         // folded in order, so only the complete PREFIX counts (a later position that happens to be complete waits for its turn)
-        unsigned long long nowv[2], now2v[2], dv[2], d2v[2];
+        unsigned long long nowv[2], now2v[2], totv[2], tot2v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t rr = jv[h] % RS_RB;
             nowv[h] = now2v[h] = 0ull;
 #pragma unroll
             for (int s = 0; s < RS_RSH; ++s) nowv[h] += w[h][s];
-            dv[h] = nowv[h] - sh.rprev[rr];
-            bool full = rs_raw_count(dv[h]) == (W & 0xffu);
-            d2v[h] = 0ull;
+            const unsigned long long d = nowv[h] - sh.rprev[rr];
+            bool full = rs_raw_count(d) == (W & 0xffu);
+            unsigned long long d2 = 0ull;
             if constexpr (MISS) {
 #pragma unroll
                 for (int s = 0; s < RS_RSH; ++s) now2v[h] += w2[h][s];
-                d2v[h] = now2v[h] - sh.rprev2[rr];
-                full = full && rs_raw_count(d2v[h]) == (W & 0xffu);
+                d2 = now2v[h] - sh.rprev2[rr];
+                full = full && rs_raw_count(d2) == (W & 0xffu);
+            }
+            totv[h] = rs_raw_value(d);
+            tot2v[h] = rs_raw_value(d2);
+            if (nranks > 1) {
+                // several ranks: this rank's part is taken once (the words are "seen" from then on), kept by window slot and pushed to every peer
+                // -- two tagged halves per sum, tag = 1 | sweep | the position's refill batch --; the dot needs the peers' parts from this
+                // rank's own mailbox, each word validating itself
+                const uint32_t slot = jv[h] & bmask;
+                const unsigned long long tag = rx_rtag(sweep_id, btv[h]);
+                if (okv[h] && !sh.rpushed[slot] && full) {
+                    sh.rprev[rr] = nowv[h];
+                    sh.rloc[slot] = totv[h];
+                    if constexpr (MISS) {
+                        sh.rprev2[rr] = now2v[h];
+                        sh.rloc2[slot] = tot2v[h];
+                    }
+                    for (int r = 0; r < nranks; ++r)
+                        if (r != rank) {
+                            unsigned long long* pw = rx_rbox(pr.mbox[r], rank) + 4u * (jv[h] % RX_RING);
+                            __hip_atomic_store(pw, tag | (totv[h] & 0xffffffffull), HG_RLX_SYSTEM);
+                            __hip_atomic_store(pw + 1, tag | (totv[h] >> 32), HG_RLX_SYSTEM);
+                            if constexpr (MISS) {
+                                __hip_atomic_store(pw + 2, tag | (tot2v[h] & 0xffffffffull), HG_RLX_SYSTEM);
+                                __hip_atomic_store(pw + 3, tag | (tot2v[h] >> 32), HG_RLX_SYSTEM);
+                            }
+                        }
+                    sh.rpushed[slot] = 1u;
+                }
+                full = okv[h] && sh.rpushed[slot] != 0u;
+                if (full) {
+                    unsigned long long t1 = sh.rloc[slot], t2 = MISS ? sh.rloc2[slot] : 0ull;
+                    for (int r = 0; r < nranks; ++r)
+                        if (r != rank) {
+                            const unsigned long long* pw = rx_rbox(pr.mbox[rank], r) + 4u * (jv[h] % RX_RING);
+                            const unsigned long long o0 = __hip_atomic_load(pw, HG_RLX_SYSTEM), o1 = __hip_atomic_load(pw + 1, HG_RLX_SYSTEM);
+                            full = full && (o0 >> 32) == (tag >> 32) && (o1 >> 32) == (tag >> 32);
+                            t1 += (o1 << 32) | (o0 & 0xffffffffull);
+                            if constexpr (MISS) {
+                                const unsigned long long o2 = __hip_atomic_load(pw + 2, HG_RLX_SYSTEM), o3 = __hip_atomic_load(pw + 3, HG_RLX_SYSTEM);
+                                full = full && (o2 >> 32) == (tag >> 32) && (o3 >> 32) == (tag >> 32);
+                                t2 += (o3 << 32) | (o2 & 0xffffffffull);
+                            }
+                        }
+                    totv[h] = t1;
+                    tot2v[h] = t2;
+                }
             }
             okv[h] = okv[h] && full;
         }
@@ -1008,13 +1116,14 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
         for (int h = 0; h < 2; ++h) {
             if (okv[h]) {
                 const uint32_t j = jv[h], slot = j & bmask, rr = j % RS_RB;
-                const unsigned long long tot = rs_raw_value(dv[h]); // what this position's batch added (wrapping 64-bit arithmetic, the arrivals taken off)
-                sh.rprev[rr] = nowv[h];
+                const unsigned long long tot = totv[h]; // what this position's batch added (wrapping 64-bit arithmetic, the arrivals taken off; several ranks: all of them)
+                if (nranks > 1) sh.rpushed[slot] = 0u; // (the slot's next position starts afresh)
+                else sh.rprev[rr] = nowv[h];
                 double s1 = (double)(long long)tot * fx_unscale;
                 double s2 = eps_sum;
                 if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R; the streamed dot weighs a missing call 3: s1' = s1 + 3 R
-                    const unsigned long long tot2 = rs_raw_value(d2v[h]);
-                    sh.rprev2[rr] = now2v[h];
+                    const unsigned long long tot2 = tot2v[h];
+                    if (nranks <= 1) sh.rprev2[rr] = now2v[h];
                     s1 = (double)(long long)(tot - 3ull * tot2) * fx_unscale; // (exact: integers)
                     s2 -= (double)(long long)tot2 * fx_unscale;
                 }
@@ -1179,6 +1288,7 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
         sh.pprev[i] = 0ull;
         sh.pprev[RS_RB + i] = 0ull;
     }
+    for (uint32_t i = (uint32_t)tid; i < B; i += RS_BLOCK) sh.rpushed[i] = 0u;
     if (tid < S_NWORDS) sh.sw[tid] = 0u;
     if (tid < W2_NCH * 4) sh.ans[tid] = 0u;
     // metadata of the first two windows, the predicted positions, the first batch

@@ -162,6 +162,7 @@ struct hgibbs_ctx {
     int res_early = 24;       // option early_advance (ResParams::early_advance)
     int res_announce = 1;     // option announce (ResParams::announce)
     int res_wend = 1;         // option window_end16 (ResParams::wend_mask)
+    int res_walker2_ranks = 1; // option walker2_ranks: several ranks run the second walker too (0: the first, as in round 3)
     double eps_abs_bound = 0.0; // (sum of eps^8)^(1/8) >= max |eps| as of the last reduce_eps_all
     int res_refill = 0;       // option refill: the streaming workgroups' form -- 1 first (hg_resident.hip.h: fused multiply-adds), 2 second (hg_streamer2.hip.h: integer matrix products), 0 auto
     int res_tune = 0;         // option res_tune: experiments of the resident kernel (ResParams::tune)
@@ -1248,6 +1249,8 @@ int hgibbs_set_option(hgibbs_t h, const char* name, int64_t value)
     } else if (!std::strcmp(name, "refill")) {
         if (value < 0 || value > 2) return fail("refill must be 0 (auto), 1 (fused multiply-adds) or 2 (integer matrix products)");
         h->res_refill = (int)value;
+    } else if (!std::strcmp(name, "walker2_ranks")) {
+        h->res_walker2_ranks = value != 0;
     } else if (!std::strcmp(name, "window_end16")) {
         h->res_wend = value != 0;
     } else if (!std::strcmp(name, "announce")) {
@@ -1528,15 +1531,15 @@ static int sweep_resident(hgibbs_ctx* h, const ResPlan& pl, double sigmaE, hgibb
     p.all_ada = h->res_all_ada ? 1 : 0;
     {
         // the second walker: every marker takes a uniform, the mixture tables and the tabulated bound fit its LDS, one rank
-        const bool w2_ok = h->res_all_ada && p.GK <= HT_LDS && G <= RS_FG && p.nranks == 1;
-        if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks)", RS_FG, HT_LDS);
+        const bool w2_ok = h->res_all_ada && p.GK <= HT_LDS && G <= RS_FG && (p.nranks == 1 || h->res_walker2_ranks);
+        if (h->res_walker == 2 && !w2_ok) return fail("hgibbs_sweep: the second walker does not apply (frozen markers, more than %d groups or %d table entries, or several ranks with walker2_ranks = 0)", RS_FG, HT_LDS);
         static const int env_walker = std::getenv("HGIBBS_WALKER") ? std::atoi(std::getenv("HGIBBS_WALKER")) : 0; // (test runs: the default walker of handles that do not set the option)
         const int want = h->res_walker ? h->res_walker : env_walker;
         p.walker = (want != 1 && w2_ok) ? 2 : 1; // (auto: the second walker where it applies)
     }
     p.pred = h->pred;
     p.tune = h->res_tune;
-    p.early_advance = h->res_early;
+    p.early_advance = p.nranks > 1 ? 0 : h->res_early; // (several ranks: the replicas must send the same messages -- an advance that depends on when the dots arrive would not be)
     p.announce = h->res_announce;
     p.wend_mask = (p.walker == 2 && pl.B >= 32u && h->res_wend) ? 15u : 0u;
     {

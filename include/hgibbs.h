@@ -157,8 +157,9 @@ int hgibbs_sweep(hgibbs_t h, const int32_t* order_host, double sigmaE, const dou
  *                   with a residual beyond the digits' range, |eps| >= 32), 1 = every wave whole columns, three vector instructions per
  *                   genotype (hg_resident.hip.h), 2 = every wave a slice of the individuals, the dots as integer matrix products over
  *                   eps's signed base-256 digits (hg_streamer2.hip.h; needs |eps| < 64: a sweep that meets a larger one fails, error 5)
- *   walker          resident engine: 0 auto (the second where it applies: every marker takes a uniform, <= 4 groups, one rank), 1 the
- *                   first walker, 2 the second (hg_walker2.hip.h; the call fails where it does not apply)
+ *   walker          resident engine: 0 auto (the second where it applies: every marker takes a uniform, <= 4 groups), 1 the
+ *                   first walker, 2 the second (hg_walker2.hip.h; the call fails where it does not apply); walker2_ranks: 1 (default) =
+ *                   several ranks run the second walker too (without early advances), 0 = they run the first
  *   announce        second walker: 1 (default) = an event that is certain (a marker whose effect is non-zero) is announced before
  *                   its draw, so that its Gram terms travel meanwhile
  *   window_end16    second walker: 1 (default) = the window ends at a multiple of sixteen positions (the second form of the streaming
