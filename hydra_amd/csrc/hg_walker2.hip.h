@@ -271,7 +271,7 @@ __device__ __forceinline__ Walk2Lds walk2_lds(uint32_t B)
 // (BC: the window as a compile-time constant -- 256, the size that is used where speed matters -- or 0: whatever the sweep's parameters say.
 // With the constant the LDS arrays are at constant addresses and the slot arithmetic is immediate: the wave's few scalar registers are not
 // spent on three dozen array bases, and a wave issues one instruction every four to five clocks whatever it is.)
-template <int DBG, int MISS, int BC>
+template <int DBG, int MISS, int BC, int RANKS> // (RANKS: several ranks -- the exchange through the mailboxes is compiled in)
 __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
 {
 #undef W2_BEXPR
@@ -461,7 +461,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                             gpb64[r] = par ? v[r] : pb;
                         }
                     }
-                    if (nranks > 1 && hit && !bad) {
+                    if (RANKS && hit && !bad) {
                         // several ranks: the 56-bit sums cross as two words each, tag << 32 | half (tag = 1 | sweep | event: self-validating), by window slot
                         const unsigned long long tag = (0x80000000ull | ((sweep_id & 0x7full) << 24) | (unsigned long long)(w2_uni(rc[R_NEV]) & 0xffffffu)) << 32;
                         for (int r = 0; r < nranks; ++r)
@@ -527,7 +527,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
                             gpb32[r] = par ? v[r] : pb;
                         }
                     }
-                    if (nranks > 1 && hit && !bad) {
+                    if (RANKS && hit && !bad) {
                         // several ranks: this rank's sum goes to every peer's mailbox, the peers' arrive in mine -- sweep << 48 | event << 24 | sum, one
                         // 8-byte store, self-validating; by window slot
                         const unsigned long long tag = (sweep_id << 48) | ((unsigned long long)(w2_uni(rc[R_NEV]) & 0xffffffu) << 24);
@@ -956,7 +956,7 @@ __device__ __attribute__((noinline)) void w2_chain(const ResParams& pr)
     }
 }
 
-template <int MISS>
+template <int MISS, int RANKS>
 __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
 {
     W2_PROLOGUE
@@ -1056,7 +1056,7 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
             }
             totv[h] = rs_raw_value(d);
             tot2v[h] = rs_raw_value(d2);
-            if (nranks > 1) {
+            if constexpr (RANKS != 0) {
                 // several ranks: this rank's part is taken once (the words are "seen" from then on), kept by window slot and pushed to every peer
                 // -- two tagged halves per sum, tag = 1 | sweep | the position's refill batch --; the dot needs the peers' parts from this
                 // rank's own mailbox, each word validating itself
@@ -1117,13 +1117,13 @@ __device__ __attribute__((noinline)) void w2_folder(const ResParams& pr)
             if (okv[h]) {
                 const uint32_t j = jv[h], slot = j & bmask, rr = j % RS_RB;
                 const unsigned long long tot = totv[h]; // what this position's batch added (wrapping 64-bit arithmetic, the arrivals taken off; several ranks: all of them)
-                if (nranks > 1) sh.rpushed[slot] = 0u; // (the slot's next position starts afresh)
+                if (RANKS) sh.rpushed[slot] = 0u; // (the slot's next position starts afresh)
                 else sh.rprev[rr] = nowv[h];
                 double s1 = (double)(long long)tot * fx_unscale;
                 double s2 = eps_sum;
                 if constexpr (MISS) { // s2 = sum of eps over the column's calls = sum of eps - R; the streamed dot weighs a missing call 3: s1' = s1 + 3 R
                     const unsigned long long tot2 = tot2v[h];
-                    if (nranks <= 1) sh.rprev2[rr] = now2v[h];
+                    if (!RANKS) sh.rprev2[rr] = now2v[h];
                     s1 = (double)(long long)(tot - 3ull * tot2) * fx_unscale; // (exact: integers)
                     s2 -= (double)(long long)tot2 * fx_unscale;
                 }
@@ -1336,10 +1336,14 @@ __device__ __attribute__((noinline)) void res_walker2(const ResParams& pr)
 
     if (wave < W2_NCH) {
         if ((uint32_t)wave < (B >= 64u ? B / 64u : 1u)) {
-            if (B == 256u) w2_chain<DBG, MISS, 256>(pr);
-            else w2_chain<DBG, MISS, 0>(pr);
+            if (pr.nranks > 1) w2_chain<DBG, MISS, 0, 1>(pr);
+            else if (B == 256u) w2_chain<DBG, MISS, 256, 0>(pr);
+            else w2_chain<DBG, MISS, 0, 0>(pr);
         }
-    } else if (wave == 4) w2_folder<MISS>(pr);
+    } else if (wave == 4) {
+        if (pr.nranks > 1) w2_folder<MISS, 1>(pr);
+        else w2_folder<MISS, 0>(pr);
+    }
     else if (wave == 5) w2_housekeeper<MISS>(pr);
     __syncthreads();
     // ---- the generator and the counters go back ----
