@@ -685,7 +685,7 @@ def main():
                        "setup_s": t_setup,
                        **({"multi_gpu_note": "no scaling curve has been measured on hardware (the pool gives one GPU); DESIGN.md section 5: the chain's "
                                              "round is latency, not streaming -- sharding the individuals buys capacity (shards of 522 K individuals per GPU), "
-                                             "predicted 0.9-1.0x at 2-8 GPUs"} if world > 1 else {}),
+                                             "predicted 0.7-0.8x of one GPU at 2-8 GPUs (one GPU: 6.7 us a round; a shard: 5.9 us + the exchange)"} if world > 1 else {}),
                        **({"missing_rate": args.missing} if args.missing else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": roof,
         }
